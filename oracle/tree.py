@@ -1,0 +1,136 @@
+"""Oracle: prediction tree, its attention masks, and the generator/discriminator tree forwards.
+
+Restates BranchPredictions/MultiStepPrediction.py (reference).  Test infrastructure only.
+A sampling rule here is a tuple (num_alterations, technique_value, params_dict).
+"""
+import torch
+
+from . import models as M
+from . import sampling as S
+
+
+class Node:
+    def __init__(self, ids, parent=None, depth=0, beam=0, probs=None):
+        self.ids, self.parent, self.depth, self.beam, self.probs = ids, parent, depth, beam, probs
+        self.children, self.kv, self.mask = [], None, None
+        self.disc_pred = self.in_value = self.alt_value = None
+
+    def sub_nodes(self):
+        """Pre-order DFS, root excluded (getSubNodes, MultiStepPrediction.py:85-90)."""
+        out = []
+        for c in self.children:
+            out.append(c)
+            out.extend(c.sub_nodes())
+        return out
+
+    def leaves(self):
+        if not self.children:
+            return [self]
+        return [l for c in self.children for l in c.leaves()]
+
+
+def depth1_mask(batch, sparse_index, S):
+    """MultiStepPrediction.py:100-111: (B,1,K,S+1); row i sees text [0..s_i] (or lower-triangular when
+    K == S) and the self column."""
+    K = len(sparse_index)
+    m = torch.zeros(batch, K, S + 1)
+    m[:, :, -1] = 1
+    for i, s in enumerate(sparse_index.tolist()):
+        m[:, i, :(i + 1 if K == S else s + 1)] = 1
+    return m.unsqueeze(1).bool()
+
+
+def deeper_mask(parent_mask, batch, K):
+    """MultiStepPrediction.py:116-127: parent mask minus its self column ‖ (K, K+1) diag + self column."""
+    new = torch.zeros(batch, K, K + 1)
+    new[:, :, -1] = 1
+    new[:, torch.arange(K), torch.arange(K)] = 1
+    return torch.cat((parent_mask[..., :-1], new.unsqueeze(1).bool()), dim=-1)
+
+
+def node_mask(node, batch, sparse_index, S):
+    if node.depth == 0:
+        return None
+    if node.mask is None:
+        if node.depth == 1:
+            node.mask = depth1_mask(batch, sparse_index, S)
+        else:
+            node.mask = deeper_mask(node_mask(node.parent, batch, sparse_index, S), batch, len(sparse_index))
+    return node.mask
+
+
+def full_past(node):
+    """getFullPast (MultiStepPrediction.py:140-152): per layer, root KV ‖ ancestors' KV in depth order."""
+    chain, n = [], node.parent
+    while n is not None:
+        chain.append(n.kv)
+        n = n.parent
+    chain.reverse()
+    return [(torch.cat([c[l][0] for c in chain], dim=-2), torch.cat([c[l][1] for c in chain], dim=-2))
+            for l in range(len(chain[0]))]
+
+
+def _add_children(node, alt_ids, alt_probs):
+    for i in range(alt_ids.shape[1]):
+        beam = i if node.parent is None else node.beam
+        node.children.append(Node(alt_ids[:, i], node, node.depth + 1, beam, alt_probs[:, :, i]))
+
+
+def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=None):
+    """multiStepGenForward (MultiStepPrediction.py:243-332).  noise_fn(shape) -> exponential noise."""
+    B, S_len = input_ids.shape
+    sparse_index = torch.as_tensor(sparse_index)
+    logits, probs, past = M.generator_forward(sd, cfg, input_ids)
+    label_p = torch.gather(probs[:, :-1], -1, input_ids[:, 1:].unsqueeze(-1)).squeeze(-1)
+    label_p = torch.cat((torch.zeros(B, 1), label_p), dim=-1)
+
+    def sample(p, n, ids, tech, block, params):
+        masked_shape = (p.shape[0], p.shape[1], p.shape[2])  # includeFinalTimeStep=True on every tree call
+        noise = noise_fn(masked_shape) if tech in (3, 6, 8, 9) else None
+        return S.sample_from_generator_distribution(p, n, ids, tech, block_sampling_of_labels=block,
+                                                    include_final_time_step=True, noise=noise, **params)
+
+    n0, t0, p0 = rules[0]
+    alt, masked = sample(probs, n0, input_ids, t0, True, p0)                    # quirk 5: step 1 blocks the label
+    alt_p = S.alt_ids_probs(probs, alt)                                         # quirk 6: unmasked probs
+    root = Node(input_ids, probs=label_p)
+    root.kv = past
+    _add_children(root, alt[:, :, 1:][:, :, sparse_index], alt_p[:, sparse_index])
+    for (n, t, p) in rules[1:]:
+        for node in root.leaves():
+            pos = (sparse_index + node.depth).unsqueeze(0).expand(B, -1)
+            mask = node_mask(node, B, sparse_index, S_len)
+            _, pr, kv = M.generator_forward(sd, cfg, node.ids, position_ids=pos, textual_past=full_past(node), mask=mask)
+            labels = torch.cat((node.ids[:, :1], node.ids[:, -1:]), dim=1)
+            alt, _ = sample(pr, n, labels, t, False, p)
+            node.kv = kv
+            _add_children(node, alt[:, :, 1:], S.alt_ids_probs(pr, alt))
+    return root, logits, probs, masked
+
+
+def multi_step_disc_forward(sd, cfg, root, sparse_index):
+    """multiStepDiscForward (MultiStepPrediction.py:335-366), inputs detached, DFS over every node."""
+    sparse_index = torch.as_tensor(sparse_index)
+    B, S_len = root.ids.shape
+
+    def visit(node):
+        if node.depth == 0:
+            out = M.discriminator_forward(sd, cfg, node.ids.detach())
+        else:
+            pos = (sparse_index + node.depth).unsqueeze(0).expand(B, -1)
+            out = M.discriminator_forward(sd, cfg, node.ids.detach(), position_ids=pos, textual_past=full_past(node),
+                                          mask=node_mask(node, B, sparse_index, S_len))
+        node.disc_pred, node.in_value, node.alt_value, node.kv = out
+        for c in node.children:
+            visit(c)
+
+    for n in [root] + root.sub_nodes():
+        n.kv = None
+    visit(root)
+    return root
+
+
+def sub_node_links(root, nodes):
+    """getSubNodeListTreeStructure (MultiStepPrediction.py:212-226)."""
+    idx = {id(n): i for i, n in enumerate(nodes)}
+    return [idx[id(c)] for c in root.children], [[idx[id(c)] for c in n.children] for n in nodes]

@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors from the real reference (FreddeFrallan/Branch-GAN).
+
+Runs ONLY in the build container, where the reference is mounted read-only at /root/reference.
+It imports the reference on CPU through the three harness-side shims recorded in SURVEY.md §8(c)
+(nothing in the reference is modified, nothing is fetched, no pretrained name is resolved) and
+writes small `.npz` fixtures next to this file.  The GPU box never sees the reference: tests read
+only the fixtures.  A fixture is data (inputs + expected outputs); no reference source is stored.
+
+Usage:  python tests/golden/make_goldens.py            (rewrites every fixture, deterministic seeds)
+
+Groups:  G1 attention, G2 sampling, G3 tree, G4 losses, G5 end-to-end tiny step.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("BRANCHGAN_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import transformers
+import transformers.modeling_utils as mu
+import transformers.pytorch_utils as pu
+
+# --- shims for transformers 5.x -------------------------------------
+mu.Conv1D = pu.Conv1D
+for _n in ("SequenceSummary", "find_pruneable_heads_and_indices", "prune_conv1d_layer"):
+    if not hasattr(mu, _n):
+        setattr(mu, _n, None)
+mu.PreTrainedModel.get_head_mask = lambda self, hm, n, *a: [None] * n
+
+from transformers import GPT2Config, GPTNeoXConfig  # noqa: E402
+
+from BranchPredictions import MultiStepPrediction as MSP  # noqa: E402
+from BranchPredictions import SamplingStrategies as SS  # noqa: E402
+from Configs import ReinforceLabelMode as RLM  # noqa: E402
+from Configs import TrainingConfig  # noqa: E402
+from Models import GanSetup  # noqa: E402
+from Models.GPT2BranchAttention.NonResidualAttention import GPT2NonResidualAttention  # noqa: E402
+from Models.Losses import DiscriminatorLoss, GeneratorLosses  # noqa: E402
+from Models.NeoXBranchAttention.NeoXNonResidualAttention import NeoXNonResidualAttention  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+T = SS.SamplingTechniques
+
+
+def neox_cfg(**kw):
+    c = GPTNeoXConfig(**kw)
+    c.rotary_pct = 0.25
+    c.rotary_emb_base = 10000
+    c.rope_scaling = None
+    return c
+
+
+def tiny_cfg(family, vocab=97, hidden=32, layers=2, heads=2, npos=64):
+    if family == "neox":
+        return neox_cfg(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=layers,
+                        num_attention_heads=heads, intermediate_size=2 * hidden,
+                        max_position_embeddings=npos, hidden_dropout=0.0, attention_dropout=0.0)
+    return GPT2Config(vocab_size=vocab, n_positions=npos, n_embd=hidden, n_layer=layers, n_head=heads,
+                      attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0)
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+class StubBuffer:
+    """Deterministic stand-in for SamplingStrategies.SAMPLE_BUFFER (the noise injection point)."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.served = []
+
+    def rand(self, shape):
+        noise = -torch.log(torch.rand(tuple(shape), generator=self.gen) + 1e-14)
+        self.served.append(noise)
+        return noise
+
+
+# =================================================================================================
+# G1 attention
+# =================================================================================================
+def build_masks(B, S, sparse, depth):
+    """Masks exactly as PredictionTreeNode.getAttentionMask builds them, for depths 1..depth."""
+    K = len(sparse)
+    root = MSP.PredictionTreeNode(torch.zeros(B, S, dtype=torch.long), sparseIndex=torch.tensor(sparse))
+    dummy_past = [(torch.zeros(B, 1, S, 2), torch.zeros(B, 1, S, 2))]
+    root.addGeneratorPredictionToNode(torch.zeros(B, 1, K, dtype=torch.long), dummy_past, None,
+                                      torch.zeros(B, K, 1))
+    node, masks = root.children[0], []
+    for d in range(1, depth + 1):
+        m = node.getAttentionMask(B, "cpu")
+        masks.append(m)
+        step_past = [(torch.zeros(B, 1, K, 2), torch.zeros(B, 1, K, 2))]
+        node.addGeneratorPredictionToNode(torch.zeros(B, 1, K, dtype=torch.long), step_past, m,
+                                          torch.zeros(B, K, 1))
+        node = node.children[0]
+    return masks
+
+
+def g1_attention():
+    out = {}
+    cases = [  # (family, H, Dh, K, S, sparse, depth, extra)
+        ("neox", 2, 8, 3, 10, [1, 4, 8], 3, {}),
+        ("neox", 4, 32, 16, 33, sorted(np.random.RandomState(1).choice(32, 16, replace=False).tolist()), 3, {}),
+        ("neox", 2, 64, 16, 33, sorted(np.random.RandomState(2).choice(32, 16, replace=False).tolist()), 2, {}),
+        ("neox", 1, 256, 3, 10, [0, 5, 8], 2, {}),
+        ("gpt2", 2, 8, 3, 10, [1, 4, 8], 3, {}),
+        ("gpt2", 4, 32, 16, 33, sorted(np.random.RandomState(3).choice(32, 16, replace=False).tolist()), 3, {}),
+        ("gpt2", 2, 64, 16, 33, sorted(np.random.RandomState(4).choice(32, 16, replace=False).tolist()), 2,
+         {"scale_attn_by_inverse_layer_idx": True, "layer_idx": 2}),
+    ]
+    B = 2
+    meta = []
+    for ci, (fam, H, Dh, K, S, sparse, depth, extra) in enumerate(cases):
+        torch.manual_seed(100 + ci)
+        if fam == "neox":
+            mod = NeoXNonResidualAttention(tiny_cfg("neox", hidden=H * Dh, heads=H))
+            fn = mod._nonResidualTextAttention
+        else:
+            cfg = tiny_cfg("gpt2", hidden=H * Dh, heads=H)
+            cfg.scale_attn_by_inverse_layer_idx = extra.get("scale_attn_by_inverse_layer_idx", False)
+            mod = GPT2NonResidualAttention(cfg, layer_idx=extra.get("layer_idx", 0))
+            fn = mod.nonResidualTextAttention
+        masks = build_masks(B, S, sparse, depth)
+        for d in range(1, depth + 1):
+            C = S + (d - 1) * K
+            q, k, v = [torch.randn(B, H, K, Dh, requires_grad=True) for _ in range(3)]
+            kc, vc = [torch.randn(B, H, C, Dh, requires_grad=True) for _ in range(2)]
+            o, w = fn(q, k, v, kc, vc, customCasualMask=masks[d - 1])
+            go = torch.randn_like(o)
+            grads = torch.autograd.grad(o, [q, k, v, kc, vc], go)
+            p = f"c{ci}_d{d}_"
+            for nm, t in zip(["q", "k", "v", "kctx", "vctx", "mask", "out", "weights", "gout",
+                              "dq", "dk", "dv", "dkctx", "dvctx"],
+                             [q, k, v, kc, vc, masks[d - 1], o, w, go, *grads]):
+                out[p + nm] = t
+        meta.append([ci, 0 if fam == "neox" else 1, H, Dh, K, S, depth,
+                     int(extra.get("scale_attn_by_inverse_layer_idx", False)), extra.get("layer_idx", 0)])
+        out[f"c{ci}_sparse"] = np.asarray(sparse, dtype=np.int64)
+    # default mask (customCasualMask=None): legacy single-step pattern A3
+    torch.manual_seed(199)
+    for fam in ("neox", "gpt2"):
+        H, Dh, Q, Kl = 2, 8, 4, 9
+        if fam == "neox":
+            fn = NeoXNonResidualAttention(tiny_cfg("neox", hidden=H * Dh, heads=H))._nonResidualTextAttention
+        else:
+            fn = GPT2NonResidualAttention(tiny_cfg("gpt2", hidden=H * Dh, heads=H), layer_idx=0).nonResidualTextAttention
+        q, k, v = [torch.randn(B, H, Q, Dh) for _ in range(3)]
+        kc, vc = [torch.randn(B, H, Kl, Dh) for _ in range(2)]
+        o, w = fn(q, k, v, kc, vc)
+        for nm, t in zip(["q", "k", "v", "kctx", "vctx", "out", "weights"], [q, k, v, kc, vc, o, w]):
+            out[f"default_{fam}_{nm}"] = t
+    out["meta"] = np.asarray(meta, dtype=np.int64)
+    save("g1_attention", **out)
+
+
+# =================================================================================================
+# G2 sampling
+# =================================================================================================
+def g2_sampling():
+    out, index = {}, []
+    gen = torch.Generator().manual_seed(2)
+    shapes = [(2, 5, 97), (2, 5, 1031), (1, 2, 50304)]
+    case = 0
+    for si, (B, Tn, V) in enumerate(shapes):
+        logits = 3.0 * torch.randn(B, Tn, V, generator=gen)
+        probs = torch.softmax(logits, dim=-1)
+        if si == 0:  # make one row's top-1 mass > 0.5 and > 0.9 (all-masked top-p row, quirk 7 / S4)
+            logits[0, 1, 11] += 30.0
+            probs = torch.softmax(logits, dim=-1)
+        ids = torch.randint(0, V, (B, Tn), generator=gen)
+        out[f"s{si}_probs"], out[f"s{si}_ids"] = probs, ids
+        techs = [(T.TOP_K, {}), (T.SAMPLE_NO_REPLACEMENT, {}),
+                 (T.TOP_P_SAMPLE_NO_REPLACEMENT, {"topP": 0.5}),
+                 (T.TOP_P_SAMPLE_NO_REPLACEMENT, {"topP": 0.9}),
+                 (T.INVERSE_TOP_K_SAMPLE_NO_REPLACEMENT, {"inverseTopK": 3})]
+        flag_sets = [(True, False), (True, True), (False, False), (False, True)] if si < 2 else [(True, True), (False, True)]
+        ns = [1, 2, 16] if si < 2 else [1, 4]
+        for tech, params in techs:
+            for (block, final) in flag_sets:
+                for n in ns:
+                    stub = StubBuffer(1000 + 2 * si + int(final))  # one noise tensor per (shape, final)
+                    SS.SAMPLE_BUFFER = stub
+                    alt, masked = SS.sampleFromGeneratorDistribution(probs, n, ids, tech, blockSamplingOfLabels=block,
+                                                                     includeFinalTimeStep=final, **params)
+                    out[f"case{case}_alt"] = alt
+                    if stub.served:
+                        assert len(stub.served) == 1
+                        out[f"s{si}_f{int(final)}_noise"] = stub.served[0]
+                    if si == 0 and n == 1:
+                        out[f"case{case}_masked"] = masked
+                    index.append([case, si, tech.value, int(block), int(final), n,
+                                  params.get("topP", -1.0), params.get("inverseTopK", -1)])
+                    case += 1
+    out["index"] = np.asarray(index, dtype=np.float64)
+    # apply_temperature
+    p = torch.softmax(torch.randn(2, 3, 97, generator=gen), dim=-1)
+    out["temp_in"] = p
+    out["temp_out_0p7"] = SS.apply_temperature(p, 0.7)
+    out["temp_out_1p5"] = SS.apply_temperature(p, 1.5)
+    save("g2_sampling", **out)
+
+
+# =================================================================================================
+# G4 losses
+# =================================================================================================
+class FakeSetup:
+    def __init__(self, mle=1.0, rl=1.0):
+        self.discriminatorLoss = torch.nn.functional.binary_cross_entropy
+        self.discValueHeadLoss = torch.nn.functional.binary_cross_entropy
+        self.generatorMleLossWeight = mle
+        self.generatorRlLossWeight = rl
+
+
+def g4_losses():
+    out, index = {}, []
+    gen = torch.Generator().manual_seed(4)
+    B, S, K, V = 3, 12, 5, 53
+    # tree: chain of 3 (A=1,1,1) and a branching tree A=(2,1): nodes pre-order [a, a1, b, b1]
+    trees = {
+        "chain3": dict(N=3, depths=[1, 2, 3], root=[0], links=[[1], [2], []]),
+        "tree2x1": dict(N=4, depths=[1, 2, 1, 2], root=[0, 2], links=[[1], [], [3], []]),
+    }
+    sparse = torch.tensor([1, 4, 6, 9, 10])
+    case = 0
+    for tname, tr in trees.items():
+        N = tr["N"]
+        r = lambda *s: torch.rand(*s, generator=gen)
+        base = dict(
+            inputScores=r(B, S), altScoresK=r(B, N, K), txtIn=r(B, S, 1), txtAlt=r(B, S, 1),
+            altIn=r(N, B, K, 1), altAlt=r(N, B, K, 1), altProbsK=r(B, N, K) * 0.5 + 1e-4,
+            logits=torch.randn(B, S, V, generator=gen), ids=torch.randint(0, V, (B, S), generator=gen))
+        for k, v in base.items():
+            out[f"{tname}_{k}"] = v
+        depthMask = torch.zeros(N, S)
+        for i, d in enumerate(tr["depths"]):
+            depthMask[i, :K] = (sparse + d <= S - 1).float()
+        out[f"{tname}_depthMask"] = depthMask
+        out[f"{tname}_depths"] = np.asarray(tr["depths"])
+        out[f"{tname}_rootLinks"] = np.asarray(tr["root"])
+        out[f"{tname}_links"] = np.asarray([(l + [-1])[0] if len(l) <= 1 else 1 / 0 for l in tr["links"]])
+
+        for mode in range(4):
+            for policy in (0, 1):
+                for tf in (True, False):
+                    leaf = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in base.items()}
+                    pad = lambda x, dim, val=0.0: torch.cat(
+                        [x, torch.full(x.shape[:dim] + (S - K,) + x.shape[dim + 1:], val)], dim=dim)
+                    altScores = pad(leaf["altScoresK"], 2)                      # GanSetup.py:151-167
+                    altAlt = pad(leaf["altAlt"], 2)                             # GanSetup.py:202-207
+                    altProbs = pad(leaf["altProbsK"], 2, 0.00001)               # MultiStepPrediction.py:59-65
+                    fpd = {"DiscValueHeads": {"txtInputPreds": leaf["txtIn"], "altInputPreds": leaf["altIn"],
+                                              "txtAlterationsPreds": leaf["txtAlt"], "altAlterationsPreds": altAlt},
+                           "SubNodeStructure": (tr["root"], tr["links"]),
+                           "TreeNodeInfo": [(d, False) for d in tr["depths"]],
+                           "AlterationProbs": altProbs}
+                    setup = FakeSetup()
+                    inL, altL, info = DiscriminatorLoss.calcDiscriminatorLoss(
+                        setup, leaf["inputScores"], altScores, 9999, depthMask, None,
+                        collectTreeDepthData=True, forwardPassData=fpd)
+                    rl = RLM.ReinforcementLearningConfig(
+                        labelMode=RLM.ReinforcementLabelMode(mode),
+                        inputIncorrectValueHeadsPolicy=RLM.IncorrectValueHeadsPolicy(policy),
+                        alterationIncorrectValueHeadsPolicy=RLM.IncorrectValueHeadsPolicy(policy),
+                        sectionWeightA=1, sectionWeightB=1, sectionWeightC=1.5, teacherForcing=tf)
+                    probs = torch.softmax(leaf["logits"], dim=-1)
+                    gl = GeneratorLosses.calcGeneratorLoss(setup, leaf["ids"], leaf["logits"], probs,
+                                                           leaf["inputScores"].detach(), altScores.detach(), fpd,
+                                                           rl, depthMask=depthMask)
+                    p = f"case{case}_"
+                    discTotal = (inL + altL) / 2 + info["ValueHeadLoss"] * 0.25
+                    gd = torch.autograd.grad(discTotal, [leaf["inputScores"], leaf["altScoresK"], leaf["txtIn"],
+                                                         leaf["txtAlt"], leaf["altAlt"]], allow_unused=True)
+                    gg = torch.autograd.grad(gl["loss"], [leaf["logits"], leaf["altProbsK"]], allow_unused=True)
+                    out[p + "disc_inputLoss"], out[p + "disc_altLoss"] = inL, altL
+                    for k, v in info.items():
+                        out[p + "disc_" + k] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+                    for k, v in gl.items():
+                        out[p + "gen_" + k] = v if isinstance(v, torch.Tensor) else np.asarray(float(v))
+                    for nm, g in zip(["dInputScores", "dAltScoresK", "dTxtIn", "dTxtAlt", "dAltAlt"], gd):
+                        out[p + nm] = g if g is not None else np.zeros(0)
+                    for nm, g in zip(["dLogits", "dAltProbsK"], gg):
+                        out[p + nm] = g if g is not None else np.zeros(0)
+                    index.append([case, list(trees).index(tname), mode, policy, int(tf)])
+                    case += 1
+    out["index"] = np.asarray(index, dtype=np.int64)
+    out["sparse"] = sparse
+    save("g4_losses", **out)
+
+
+# =================================================================================================
+# G3 tree + G5 end-to-end tiny step
+# =================================================================================================
+def dump_tree(root, prefix, out):
+    nodes = root.getSubNodes()
+    for i, n in enumerate(nodes):
+        out[f"{prefix}node{i}_ids"] = n.ids
+        out[f"{prefix}node{i}_probs"] = n.probs
+        out[f"{prefix}node{i}_meta"] = np.asarray([n.depth, n.beam, int(n.isRandom),
+                                                   -1 if n.parent is root else nodes.index(n.parent)])
+        if n.attMask is not None:
+            out[f"{prefix}node{i}_attmask"] = n.attMask
+    out[f"{prefix}root_probs"] = root.probs
+    return nodes
+
+
+def g3_g5(family, tag, rules_spec, seed, sparse, B=2, S=12):
+    out = {}
+    torch.manual_seed(seed)
+    cfg_g = tiny_cfg(family)
+    cfg_d = tiny_cfg(family, hidden=16, heads=2)
+    setup = GanSetup.GannSetup(cfg_g, cfg_d)
+    # post_init() leaves heads at N(0, .02): scale up a little so scores are not all ~0.5
+    with torch.no_grad():
+        for p in setup.parameters():
+            p.mul_(3.0)
+    setup.eval()
+    for k, v in setup.state_dict().items():
+        out["sd::" + k] = v
+    V = cfg_g.vocab_size
+    ids = torch.randint(0, V, (B, S))
+    out["inputIDs"], out["sparseIndex"] = ids, np.asarray(sparse, dtype=np.int64)
+
+    def mk_rules():
+        return [SS.SamplingRule(a, T(t), dict(p)) for (a, t, p) in rules_spec]
+
+    out["rules"] = np.asarray([[a, t] for (a, t, _) in rules_spec], dtype=np.int64)
+    stub = StubBuffer(seed + 7)
+    SS.SAMPLE_BUFFER = stub
+    sp = torch.tensor(sparse)
+    # --- G3: tree pieces --------------------------------------------------------------------------
+    root, firstPred, firstProbs, maskedProbs = MSP.multiStepGenForward(setup.generator, ids, mk_rules(), "cpu",
+                                                                       sparseIndex=sp)
+    nodes = dump_tree(root, "gen_", out)
+    out["gen_logits"], out["gen_firstProbs"] = firstPred.logits, firstProbs
+    for i, nz in enumerate(stub.served):
+        out[f"noise{i}"] = nz
+    MSP.multiStepDiscForward(setup.discriminator, root, "cpu", dualValueHeads=True)
+    out["disc_root_pred"] = root.discPreds.prediction
+    out["disc_root_inV"], out["disc_root_altV"] = root.valueHeadData["InputValue"], root.valueHeadData["AlterationsValue"]
+    for i, n in enumerate(nodes):
+        out[f"disc_node{i}_pred"] = n.discPreds.prediction
+        out[f"disc_node{i}_inV"], out[f"disc_node{i}_altV"] = n.valueHeadData["InputValue"], n.valueHeadData["AlterationsValue"]
+    # --- G5: the whole step through GannSetup, fresh noise stub with the same seed ----------------
+    SS.SAMPLE_BUFFER = StubBuffer(seed + 7)
+    conf = TrainingConfig.SamplingConfig(mk_rules(), numSampleSequences=len(sparse), sparseIndex=sparse)
+    rl = RLM.ReinforcementLearningConfig(labelMode=RLM.ReinforcementLabelMode.ALTERATIONS_AND_INPUT_UNWEIGHTED,
+                                         sectionWeightA=1, sectionWeightB=1, sectionWeightC=1.5, teacherForcing=True)
+    setup.zero_grad()
+    discLosses, genLosses = setup.trainForwardPassNoMetrics(ids, conf, 9999, collectTreeDepthData=True,
+                                                            reinforcementLearningConfig=rl)
+    genLosses["loss"].backward()
+    discLosses["loss"].backward()
+    for k, v in discLosses.items():
+        out["dloss::" + k] = v if isinstance(v, torch.Tensor) else np.asarray(float(v))
+    for k, v in genLosses.items():
+        out["gloss::" + k] = v if isinstance(v, torch.Tensor) else np.asarray(float(v))
+    for k, p in setup.named_parameters():
+        out["grad::" + k] = p.grad if p.grad is not None else np.zeros(0, dtype=np.float32)
+    save(f"g35_{tag}", **out)
+
+
+def main():
+    torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
+    g1_attention()
+    g2_sampling()
+    g4_losses()
+    TK, NR = T.TOP_K.value, T.SAMPLE_NO_REPLACEMENT.value
+    g3_g5("neox", "neox_chain4", [(1, TK, {})] * 4, 11, [1, 3, 6, 8, 10])
+    g3_g5("neox", "neox_tree211", [(2, TK, {}), (1, NR, {}), (1, TK, {})], 12, [0, 2, 5, 9])
+    g3_g5("gpt2", "gpt2_chain3", [(1, TK, {})] * 3, 13, [1, 3, 6, 8, 10])
+    g3_g5("gpt2", "gpt2_tree21", [(2, NR, {}), (1, TK, {})], 14, [2, 4, 7, 10])
+
+
+if __name__ == "__main__":
+    main()
