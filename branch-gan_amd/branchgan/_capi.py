@@ -1,0 +1,114 @@
+"""ctypes binding of libbranchgan_hip.so (the C-ABI declared in include/branchgan.h).
+
+There is no fallback: if the library is missing or a call fails, this raises.  torch is used only for
+device memory and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbranchgan_hip.so")
+
+BG_F32, BG_BF16 = 0, 1
+MAX_TOPN, MAX_BLOCKED, MAX_SLOTS, MAX_GATHER = 64, 8, 64, 80
+
+c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class AttnShape(ctypes.Structure):
+    _fields_ = [("dtype", c_i32), ("B", c_i32), ("H", c_i32), ("NQ", c_i32), ("K", c_i32), ("Dh", c_i32), ("S_text", c_i32),
+                ("n_slots", c_i32), ("max_path", c_i32), ("scale", c_f32),
+                ("q_sb", c_i64), ("q_sh", c_i64), ("q_sn", c_i64), ("q_sk", c_i64),
+                ("o_sb", c_i64), ("o_sh", c_i64), ("o_sn", c_i64), ("o_sk", c_i64),
+                ("t_sb", c_i64), ("t_sh", c_i64), ("t_ss", c_i64),
+                ("s_sb", c_i64), ("s_sh", c_i64), ("s_sk", c_i64)]
+
+
+class DiscLossShape(ctypes.Structure):
+    _fields_ = [("B", c_i32), ("S", c_i32), ("N", c_i32), ("K", c_i32), ("n_update", c_i32), ("n_root", c_i32),
+                ("max_child", c_i32)]
+
+
+class RlLossShape(ctypes.Structure):
+    _fields_ = [("B", c_i32), ("S", c_i32), ("N", c_i32), ("K", c_i32), ("wA", c_f32), ("wB", c_f32), ("wC", c_f32),
+                ("ignore_input", c_i32), ("ignore_alt", c_i32), ("use_depth_mask", c_i32)]
+
+
+# name -> (restype, argtypes); every symbol include/branchgan.h declares
+SIGNATURES = {
+    "bg_last_error": (ctypes.c_char_p, []),
+    "bg_version": (c_i32, []),
+    "bg_device_arch": (c_i32, [ctypes.c_char_p, c_sz]),
+    "bg_topn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "bg_topn_select": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp,
+                               c_vp, c_sz, c_vp]),
+    "bg_topp_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
+    "bg_topp_select": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_softmax_stats_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "bg_softmax_stats_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "bg_branch_attn_fwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "bg_branch_attn_bwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                   ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_vp]),
+    "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
+    "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
+    "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),
+    "bg_rl_loss_bwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library once.  Raises if it is not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU or PyTorch fallback for the HIP kernels)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:                  # calling it later raises AttributeError; tests/test_capi.py is strict
+                continue
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    """Names from SIGNATURES the built library really exports (used by the no-GPU load test)."""
+    handle = ctypes.CDLL(LIB_PATH)
+    return [n for n in SIGNATURES if hasattr(handle, n)]
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed (code {code}): {lib().bg_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else c_vp(t.data_ptr())
+
+
+def stream_ptr():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return BG_F32
+    if t.dtype == torch.bfloat16:
+        return BG_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}: the HIP kernels take float32 or bfloat16")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("branchgan HIP ops need tensors on an MI355X (cuda device); there is no CPU path")

@@ -1,0 +1,264 @@
+"""Tensor-level wrappers of the C-ABI (include/branchgan.h) with autograd where the path differentiates.
+
+Everything here launches hand-written gfx950 kernels through ctypes on torch's current HIP stream.
+torch supplies device memory and autograd bookkeeping only; there is no CPU or eager fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _capi as C
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch for kernels that need one (top-n partials)."""
+    if nbytes == 0:
+        return None
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[device] = ws
+    return ws
+
+
+def _rows_2d(t):
+    """(…, V) -> 2-D view with a contiguous last dim and one row stride (copy only if it must)."""
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(-1) != 1:
+        t2 = t2.contiguous()
+    return t2
+
+
+# ---------------------------------------------------------------------------------------------------
+# sampling
+# ---------------------------------------------------------------------------------------------------
+def topn_select(scores, n, noise=None, blocked=None, blocked_value=0.0, row_map=None, return_keys=False):
+    """bg_topn_select.  scores (R_in, V) fp32/bf16; noise (R, V) fp32 or None; blocked (R, nb) int64 or None;
+    row_map (R,) int64 or None (R = R_in without it).  Returns ids (R, n) int64 [, keys (R, n) fp32]."""
+    C.require_cuda(scores, noise, blocked, row_map)
+    scores = _rows_2d(scores)
+    rows = scores.shape[0] if row_map is None else row_map.shape[0]
+    V = scores.shape[1]
+    if noise is not None:
+        noise = _rows_2d(noise)
+        if noise.dtype != torch.float32 or noise.shape != (rows, V):
+            raise ValueError(f"noise must be float32 of shape ({rows}, {V}), got {noise.dtype} {tuple(noise.shape)}")
+    nb = 0
+    if blocked is not None:
+        blocked = blocked.reshape(rows, -1).contiguous().to(torch.int64)
+        nb = blocked.shape[1]
+    if row_map is not None:
+        row_map = row_map.contiguous().to(torch.int64)
+    ids = torch.empty((rows, n), dtype=torch.int64, device=scores.device)
+    keys = torch.empty((rows, n), dtype=torch.float32, device=scores.device) if return_keys else None
+    lib = C.lib()
+    ws_bytes = lib.bg_topn_workspace_bytes(rows, V, n)
+    ws = _workspace(ws_bytes, scores.device)
+    C.check(lib.bg_topn_select(C.ptr(scores), C.dtype_code(scores), rows, V, scores.stride(0), C.ptr(row_map),
+                               C.ptr(noise), noise.stride(0) if noise is not None else 0,
+                               C.ptr(blocked), nb, float(blocked_value), n, C.ptr(ids), C.ptr(keys),
+                               C.ptr(ws), ws.numel() if ws is not None else 0, C.stream_ptr()), "bg_topn_select")
+    return (ids, keys) if return_keys else ids
+
+
+def topp_select(probs, n, noise, top_p, blocked=None, return_keys=False):
+    """bg_topp_select.  probs, noise (R, V) fp32.  Returns ids (R, n) int64 [, keys]."""
+    C.require_cuda(probs, noise, blocked)
+    probs, noise = _rows_2d(probs), _rows_2d(noise)
+    if probs.dtype != torch.float32 or noise.dtype != torch.float32 or probs.shape != noise.shape:
+        raise ValueError("top-p takes float32 probs and noise of the same shape")
+    rows, V = probs.shape
+    nb = 0
+    if blocked is not None:
+        blocked = blocked.reshape(rows, -1).contiguous().to(torch.int64)
+        nb = blocked.shape[1]
+    ids = torch.empty((rows, n), dtype=torch.int64, device=probs.device)
+    keys = torch.empty((rows, n), dtype=torch.float32, device=probs.device) if return_keys else None
+    lib = C.lib()
+    ws_bytes = lib.bg_topp_workspace_bytes(rows, V, n)
+    ws = _workspace(ws_bytes, probs.device)
+    C.check(lib.bg_topp_select(C.ptr(probs), rows, V, probs.stride(0), C.ptr(noise), noise.stride(0), C.ptr(blocked), nb,
+                               float(top_p), n, C.ptr(ids), C.ptr(keys), C.ptr(ws), ws.numel() if ws is not None else 0,
+                               C.stream_ptr()), "bg_topp_select")
+    return (ids, keys) if return_keys else ids
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused softmax statistics (lse, log-probs of chosen ids) with backward into the logits
+# ---------------------------------------------------------------------------------------------------
+class _SoftmaxStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, ids):
+        C.require_cuda(logits, ids)
+        x = _rows_2d(logits)
+        rows, V = x.shape
+        ids2 = ids.reshape(rows, -1).contiguous().to(torch.int64)
+        n_ids = ids2.shape[1]
+        lse = torch.empty(rows, dtype=torch.float32, device=x.device)
+        logp = torch.empty((rows, n_ids), dtype=torch.float32, device=x.device)
+        C.check(C.lib().bg_softmax_stats_fwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids,
+                                             C.ptr(lse), C.ptr(logp), C.stream_ptr()), "bg_softmax_stats_fwd")
+        ctx.save_for_backward(x, ids2, lse)
+        ctx.in_shape = logits.shape
+        ctx.mark_non_differentiable(ids)
+        return lse.view(logits.shape[:-1]), logp.view(*logits.shape[:-1], n_ids)
+
+    @staticmethod
+    def backward(ctx, g_lse, g_logp):
+        x, ids2, lse = ctx.saved_tensors
+        rows, V = x.shape
+        n_ids = ids2.shape[1]
+        g_lse = g_lse.reshape(rows).contiguous().float() if g_lse is not None else None
+        g_logp = g_logp.reshape(rows, n_ids).contiguous().float() if g_logp is not None else None
+        dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+        C.check(C.lib().bg_softmax_stats_bwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids, C.ptr(lse),
+                                             C.ptr(g_lse), C.ptr(g_logp), C.ptr(dx), C.stream_ptr()), "bg_softmax_stats_bwd")
+        return dx.view(ctx.in_shape), None
+
+
+def softmax_stats(logits, ids):
+    """-> (lse (...,), logp (..., n_ids)): log-sum-exp over the vocabulary and log-softmax at `ids` (id < 0: 0)."""
+    return _SoftmaxStats.apply(logits, ids)
+
+
+# ---------------------------------------------------------------------------------------------------
+# branch attention
+# ---------------------------------------------------------------------------------------------------
+_path_cache = {}
+
+
+def path_tables(paths, device):
+    """paths: list (one per query node) of slot-index lists -> cached device (path int32 [NQ][max_path], path_len)."""
+    key = (tuple(tuple(p) for p in paths), str(device))
+    hit = _path_cache.get(key)
+    if hit is None:
+        max_path = max((len(p) for p in paths), default=0)
+        tab = torch.zeros((len(paths), max(max_path, 1)), dtype=torch.int32)
+        for i, p in enumerate(paths):
+            tab[i, :len(p)] = torch.tensor(p, dtype=torch.int32)
+        lens = torch.tensor([len(p) for p in paths], dtype=torch.int32)
+        hit = (tab.to(device), lens.to(device), max_path)
+        _path_cache[key] = hit
+    return hit
+
+
+def _ptr_array(tensors):
+    arr = (C.c_vp * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _attn_shape(q, k_text, slots_k, scale, max_path, out):
+    B, H, NQ, K, Dh = q.shape
+    sh = C.AttnShape()
+    sh.dtype = C.dtype_code(q)
+    sh.B, sh.H, sh.NQ, sh.K, sh.Dh = B, H, NQ, K, Dh
+    sh.S_text = 0 if k_text is None else k_text.shape[2]
+    sh.n_slots, sh.max_path, sh.scale = len(slots_k), max_path, float(scale)
+    sh.q_sb, sh.q_sh, sh.q_sn, sh.q_sk = q.stride()[:4]
+    sh.o_sb, sh.o_sh, sh.o_sn, sh.o_sk = out.stride()[:4]
+    if k_text is not None:
+        sh.t_sb, sh.t_sh, sh.t_ss = k_text.stride()[:3]
+    if slots_k:
+        sh.s_sb, sh.s_sh, sh.s_sk = slots_k[0].stride()[:3]
+    return sh
+
+
+def _unit_last(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class _BranchAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k_text, v_text, ctx_len, path, path_len, max_path, scale, n_slots, *slots):
+        slots_k, slots_v = list(slots[:n_slots]), list(slots[n_slots:])
+        C.require_cuda(q, k_text, v_text, ctx_len, *slots)
+        q = _unit_last(q)
+        k_text, v_text = _unit_last(k_text), _unit_last(v_text)
+        if k_text.stride() != v_text.stride():
+            k_text, v_text = k_text.contiguous(), v_text.contiguous()
+        if slots_k:
+            ref = slots_k[0].stride()
+            if any(t.stride() != ref or t.stride(-1) != 1 for t in slots_k + slots_v):
+                slots_k = [t.contiguous() for t in slots_k]
+                slots_v = [t.contiguous() for t in slots_v]
+        B, H, NQ, K, Dh = q.shape
+        out = torch.empty((B, H, NQ, K, Dh), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=q.device)
+        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
+        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
+                                           _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
+                                           C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots_k, *slots_v)
+        ctx.meta = (max_path, scale, len(slots_k))
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        max_path, scale, n_slots = ctx.meta
+        q, k_text, v_text, ctx_len, path, path_len, out, lse = ctx.saved_tensors[:8]
+        slots_k = list(ctx.saved_tensors[8:8 + n_slots])
+        slots_v = list(ctx.saved_tensors[8 + n_slots:])
+        dout = dout.contiguous()
+        dq = torch.empty_like(out)
+        dk_text = torch.empty_strided(k_text.shape, k_text.stride(), dtype=k_text.dtype, device=k_text.device)
+        dv_text = torch.empty_strided(k_text.shape, k_text.stride(), dtype=k_text.dtype, device=k_text.device)
+        dks = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in slots_k]
+        dvs = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in slots_k]
+        delta = torch.empty_like(lse)
+        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
+        C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
+                                           _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
+                                           C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text),
+                                           _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
+                "bg_branch_attn_bwd")
+        return (dq, dk_text, dv_text, None, None, None, None, None, None, *dks, *dvs)
+
+
+def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=None, scale=None):
+    """q (B,H,NQ,K,Dh) [or (B,H,K,Dh) = one node]; k_text/v_text (B,H,S,Dh); ctx_len int32 (K,) device;
+    slots_k/v: lists of (B,H,K,Dh); paths: per query node, the slot indices it may see (ancestors + itself).
+    Returns (out like q, lse fp32)."""
+    squeeze = q.dim() == 4
+    if squeeze:
+        q = q.unsqueeze(2)
+    NQ = q.shape[2]
+    if paths is None:
+        paths = [list(range(len(slots_k)))] * NQ
+    if len(paths) != NQ:
+        raise ValueError(f"{len(paths)} paths for {NQ} query nodes")
+    for p in paths:
+        if any(s < 0 or s >= len(slots_k) for s in p):
+            raise ValueError("path refers to a slot that was not passed")
+    if len(slots_k) != len(slots_v):
+        raise ValueError("slots_k and slots_v differ in length")
+    if ctx_len.dtype != torch.int32 or ctx_len.numel() != q.shape[3]:
+        raise ValueError("ctx_len must be int32 with one entry per branch point")
+    if k_text.shape[-1] != q.shape[-1]:
+        raise ValueError("head dims differ")
+    path, path_len, max_path = path_tables(paths, q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    out, lse = _BranchAttention.apply(q, k_text, v_text, ctx_len.contiguous(), path, path_len, max_path, float(scale),
+                                      len(slots_k), *slots_k, *slots_v)
+    return (out.squeeze(2), lse.squeeze(2)) if squeeze else (out, lse)
+
+
+_arange_cache = {}
+
+
+def causal_attention(q, k, v, scale=None):
+    """Root causal pass as the same kernel: query i sees keys j <= i + (S - T).  q (B,H,T,Dh), k/v (B,H,S,Dh)."""
+    T_, S_ = q.shape[2], k.shape[2]
+    key = (T_, S_, str(q.device))
+    ctx = _arange_cache.get(key)
+    if ctx is None:
+        ctx = torch.arange(S_ - T_ + 1, S_ + 1, dtype=torch.int32, device=q.device)
+        _arange_cache[key] = ctx
+    out, lse = branch_attention(q, k, v, ctx, (), (), paths=[[]], scale=scale)
+    return out, lse

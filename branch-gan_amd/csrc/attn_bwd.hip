@@ -1,0 +1,392 @@
+// Branch attention backward: three deterministic kernels (no atomics), recomputing P from the saved LSE.
+//
+//   1. dq kernel      (query on the lane, same shape as the forward): delta = rowsum(dO∘O), dQ.
+//   2. dkv kernel     (key on the lane): each wave owns 32 text keys and sweeps the query tiles that can see
+//                     them; dK/dV accumulate in registers and are stored once (every text row is written).
+//   3. slots kernel   per-row VALU: dK/dV of each branch slot = sum over the query nodes whose path holds it.
+// Gradients of the reference ops cited in attn_fwd.hip (autograd of NeoXNonResidualAttention.py:183-232 /
+// NonResidualAttention.py:119-172).  See include/branchgan.h: bg_branch_attn_bwd.
+#include "attn_common.h"
+
+namespace bg {
+
+size_t attn_fwd_lds_bytes(int dtype, int Dh);
+int validate_attn_shape(const bg_attn_shape* s, const char* who);
+int check_aligned16(const void* p, const char* who, const char* name);
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
+  using L = Lds<T, DH>;
+  constexpr int NDT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* k_row = (T*)smem;
+  T* v_row = k_row + L::ROW_ELEMS;
+  T* k_col = v_row + L::ROW_ELEMS;  // bf16 only
+  int* red = (int*)(k_col + (sizeof(T) == 4 ? 0 : L::COL_ELEMS));
+
+  const bg_attn_shape& sh = a.sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int R = sh.NQ * sh.K;
+  const int rq = blockIdx.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
+  const bool valid = rq < R;
+  const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
+  int ctx = valid ? a.ctx_len[kq] : 0;
+  ctx = min(ctx, sh.S_text);
+
+  const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)kq * sh.q_sk;
+  const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)kq * sh.o_sk;
+  const T* q_row = (const T*)a.q + qoff;
+  const T* o_row = (const T*)a.out + ooff;
+  const T* do_row = (const T*)a.dout + ooff;
+  const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
+
+  RowFrag<T, DH> qf, dof;
+  qf.load(q_row, valid, h);
+  dof.load(do_row, valid, h);
+  const float delta = pair_dot<T, DH>(do_row, o_row, h, valid);
+  const float lse = valid ? a.lse[stat] : 0.f;
+  if (valid && h == 0) a.delta[stat] = delta;
+
+  int wave_ctx = ctx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_ctx = max(wave_ctx, __shfl_xor(wave_ctx, o));
+  if (lane == 0) red[wave] = wave_ctx;
+  __syncthreads();
+  const int block_ctx = max(max(red[0], red[1]), max(red[2], red[3]));
+
+  f32x16 dq[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+  for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
+    __syncthreads();
+    if constexpr (sizeof(T) == 4) stage_tile<T, DH, true, false>(kt, sh.t_ss, kb, sh.S_text, k_row, nullptr, tid, 256);
+    else stage_tile<T, DH, true, true>(kt, sh.t_ss, kb, sh.S_text, k_row, k_col, tid, 256);
+    stage_tile<T, DH, true, false>(vt, sh.t_ss, kb, sh.S_text, v_row, nullptr, tid, 256);
+    __syncthreads();
+    if (kb >= wave_ctx) continue;
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    mma_reduce_d<T, DH>(s, k_row, lane, [&](int t) { return qf.get(t, h); });
+    mma_reduce_d<T, DH>(dp, v_row, lane, [&](int t) { return dof.get(t, h); });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb + tile_row(r, h);
+      const float p = (key < ctx) ? __expf(s[r] * sh.scale - lse) : 0.f;
+      s[r] = p * (dp[r] - delta) * sh.scale;  // dS^T
+    }
+    mma_reduce_rows<T, DH, 0, NDT>(dq, s, sizeof(T) == 4 ? k_row : k_col, lane);
+  }
+
+  const int plen = valid ? a.path_len[n] : 0;
+  for (int p = 0; p < sh.max_path; ++p) {
+    const bool act = p < plen;
+    const int slot = act ? a.path[n * sh.max_path + p] : 0;
+    const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
+    const T* kr = nullptr;
+    const T* vr = nullptr;
+    for (int sidx = 0; sidx < sh.n_slots; ++sidx)
+      if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
+    const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
+    const float dpv = pair_dot<T, DH>(do_row, vr, h, act);
+    if (act) {
+      const float pw = __expf(sc - lse);
+      axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
+    }
+  }
+  store_rowvec<T, DH>(dq, 1.f, (T*)a.dq + ooff, h, valid);
+}
+
+static size_t attn_dq_lds_bytes(int dtype, int Dh) {
+  if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8) + Dh * (ATT_TILE + 4)) * 2 + 64;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PASS splits the d range of the accumulators for DH = 256 (two launches, 128 d each).
+template <typename T, int DH, int DT0, int DT1>
+__global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
+  using L = Lds<T, DH>;
+  constexpr int NDT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* q_row_l = (T*)smem;
+  T* do_row_l = q_row_l + L::ROW_ELEMS;
+  T* q_col_l = do_row_l + L::ROW_ELEMS;                                   // bf16 only
+  T* do_col_l = q_col_l + (sizeof(T) == 4 ? 0 : L::COL_ELEMS);            // bf16 only
+  float* lse_s = (float*)(do_col_l + (sizeof(T) == 4 ? 0 : L::COL_ELEMS));
+  float* delta_s = lse_s + ATT_TILE;
+  int* ctx_s = (int*)(delta_s + ATT_TILE);
+
+  const bg_attn_shape& sh = a.sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int R = sh.NQ * sh.K;
+  const int key0_block = blockIdx.x * (ATT_WAVES * ATT_TILE);
+  const int key0_wave = key0_block + wave * ATT_TILE;
+  const int key = key0_wave + (lane & 31);
+  const bool kvalid = key < sh.S_text;
+  const T* k_rowp = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+  const T* v_rowp = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+  RowFrag<T, DH> kf, vf;
+  kf.load(k_rowp, kvalid, h);
+  vf.load(v_rowp, kvalid, h);
+
+  f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = DT0; dt < DT1; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  for (int q0 = 0; q0 < R; q0 += ATT_TILE) {
+    // queries of this tile, their ctx: skip the tile if none of them reaches this workgroup's keys
+    const int rq = q0 + (lane & 31);
+    const bool qv = rq < R;
+    const int n = qv ? rq / sh.K : 0, kq = qv ? rq % sh.K : 0;
+    const int ctx = qv ? min(a.ctx_len[kq], sh.S_text) : 0;
+    int tile_ctx = ctx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tile_ctx = max(tile_ctx, __shfl_xor(tile_ctx, o));
+    if (tile_ctx <= key0_block) continue;  // uniform over the workgroup
+
+    __syncthreads();
+    // stage Q and dO rows of the tile: row i of the tile = query q0 + i (rows live at arbitrary strides,
+    // so gather them one query at a time: 8 threads per query row)
+    {
+      constexpr int VEC = 16 / sizeof(T);
+      constexpr int CPR = DH / VEC;  // 16-byte chunks per row
+      for (int c = tid; c < ATT_TILE * CPR; c += 256) {
+        const int r = c / CPR, d0 = (c % CPR) * VEC;
+        const int rr = q0 + r;
+        const bool ok = rr < R;
+        const int nn = ok ? rr / sh.K : 0, kk = ok ? rr % sh.K : 0;
+        const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)nn * sh.q_sn + (int64_t)kk * sh.q_sk + d0;
+        const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)nn * sh.o_sn + (int64_t)kk * sh.o_sk + d0;
+        if constexpr (sizeof(T) == 4) {
+          f32x4 qv4 = {0.f, 0.f, 0.f, 0.f}, dv4 = {0.f, 0.f, 0.f, 0.f};
+          if (ok) { qv4 = *(const f32x4*)((const T*)a.q + qoff); dv4 = *(const f32x4*)((const T*)a.dout + ooff); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            q_row_l[r * L::RSTRIDE + d0 + j] = qv4[j];
+            do_row_l[r * L::RSTRIDE + d0 + j] = dv4[j];
+          }
+        } else {
+          bf16x8 qv8, dv8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { qv8[j] = (bf16_t)0.0f; dv8[j] = (bf16_t)0.0f; }
+          if (ok) { qv8 = *(const bf16x8*)((const T*)a.q + qoff); dv8 = *(const bf16x8*)((const T*)a.dout + ooff); }
+          *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = qv8;
+          *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = dv8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            q_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = qv8[j];
+            do_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = dv8[j];
+          }
+        }
+      }
+      if (tid < ATT_TILE) {
+        const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
+        lse_s[tid] = qv ? a.lse[stat] : 0.f;
+        delta_s[tid] = qv ? a.delta[stat] : 0.f;
+        ctx_s[tid] = ctx;  // 0 for invalid queries: masks everything
+      }
+    }
+    __syncthreads();
+    if (tile_ctx <= key0_wave) continue;  // wave-uniform: nothing in this tile sees this wave's keys
+
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    // S[query][key] = Q·K^T, dP[query][key] = dO·V^T  (tile rows = queries, column = this lane's key)
+    mma_reduce_d<T, DH>(s, q_row_l, lane, [&](int t) { return kf.get(t, h); });
+    mma_reduce_d<T, DH>(dp, do_row_l, lane, [&](int t) { return vf.get(t, h); });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_row(r, h);
+      const float p = (key < ctx_s[row]) ? __expf(s[r] * sh.scale - lse_s[row]) : 0.f;
+      dp[r] = p * (dp[r] - delta_s[row]) * sh.scale;  // dS
+      s[r] = p;                                       // P
+    }
+    mma_reduce_rows<T, DH, DT0, DT1>(dv, s, sizeof(T) == 4 ? do_row_l : do_col_l, lane);   // dV^T += dO^T·P
+    mma_reduce_rows<T, DH, DT0, DT1>(dk, dp, sizeof(T) == 4 ? q_row_l : q_col_l, lane);    // dK^T += Q^T·dS
+  }
+
+  if (kvalid) {
+    T* dk_row = (T*)a.dk_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+    T* dv_row = (T*)a.dv_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+#pragma unroll
+    for (int dt = DT0; dt < DT1; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * h;
+        if constexpr (sizeof(T) == 4) {
+          f32x4 ok, ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ok[j] = dk[dt][4 * g + j]; ov[j] = dv[dt][4 * g + j]; }
+          *(f32x4*)(dk_row + d) = ok;
+          *(f32x4*)(dv_row + d) = ov;
+        } else {
+          bf16x4 ok, ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ok[j] = (bf16_t)dk[dt][4 * g + j]; ov[j] = (bf16_t)dv[dt][4 * g + j]; }
+          *(bf16x4*)(dk_row + d) = ok;
+          *(bf16x4*)(dv_row + d) = ov;
+        }
+      }
+    }
+  }
+}
+
+static size_t attn_dkv_lds_bytes(int dtype, int Dh) {
+  if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 3 * ATT_TILE * 4 + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8) + 2 * Dh * (ATT_TILE + 4)) * 2 + 3 * ATT_TILE * 4 + 64;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grid (n_slots, B*H), 256 threads: 8 lanes per branch point k, each lane owns DH/8 contiguous features.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) {
+  constexpr int LPR = 8, PER = DH / LPR;
+  const bg_attn_shape& sh = a.sh;
+  const int slot = blockIdx.x, bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int tid = threadIdx.x, sub = tid % LPR;
+  const T* kslot = nullptr;
+  const T* vslot = nullptr;
+  T* dkslot = nullptr;
+  T* dvslot = nullptr;
+  for (int sidx = 0; sidx < sh.n_slots; ++sidx)
+    if (sidx == slot) { kslot = (const T*)a.k_slots[sidx]; vslot = (const T*)a.v_slots[sidx]; dkslot = (T*)a.dk_slots[sidx]; dvslot = (T*)a.dv_slots[sidx]; }
+
+  for (int k0 = 0; k0 < sh.K; k0 += 256 / LPR) {
+    const int kq = k0 + tid / LPR;
+    const bool valid = kq < sh.K;
+    const int64_t soff = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)(valid ? kq : 0) * sh.s_sk + sub * PER;
+    float kk[PER], vv[PER], dk[PER], dv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      kk[j] = valid ? to_f32(kslot[soff + j]) : 0.f;
+      vv[j] = valid ? to_f32(vslot[soff + j]) : 0.f;
+      dk[j] = 0.f;
+      dv[j] = 0.f;
+    }
+    for (int n = 0; n < sh.NQ; ++n) {
+      bool member = false;
+      const int plen = a.path_len[n];
+      for (int p = 0; p < plen; ++p) member |= (a.path[n * sh.max_path + p] == slot);
+      if (!member) continue;  // uniform
+      const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)(valid ? kq : 0) * sh.q_sk + sub * PER;
+      const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)(valid ? kq : 0) * sh.o_sk + sub * PER;
+      float qq[PER], dd[PER];
+      float sdot = 0.f, pdot = 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        qq[j] = valid ? to_f32(((const T*)a.q)[qoff + j]) : 0.f;
+        dd[j] = valid ? to_f32(((const T*)a.dout)[ooff + j]) : 0.f;
+        sdot = fmaf(qq[j], kk[j], sdot);
+        pdot = fmaf(dd[j], vv[j], pdot);
+      }
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) { sdot += __shfl_xor(sdot, o); pdot += __shfl_xor(pdot, o); }
+      const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + (valid ? kq : 0);
+      const float pw = valid ? __expf(sdot * sh.scale - a.lse[stat]) : 0.f;
+      const float ds = valid ? pw * (pdot - a.delta[stat]) * sh.scale : 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        dk[j] = fmaf(ds, qq[j], dk[j]);
+        dv[j] = fmaf(pw, dd[j], dv[j]);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        dkslot[soff + j] = from_f32<T>(dk[j]);
+        dvslot[soff + j] = from_f32<T>(dv[j]);
+      }
+    }
+  }
+}
+
+template <typename T>
+static void launch_bwd(const AttnArgs& a, hipStream_t st) {
+  const bg_attn_shape& sh = a.sh;
+  const dim3 block(256);
+  const dim3 grid_q((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));
+  const dim3 grid_k((unsigned)cdiv((int64_t)sh.S_text, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));
+  const dim3 grid_s((unsigned)sh.n_slots, (unsigned)(sh.B * sh.H));
+  const size_t lq = attn_dq_lds_bytes(sh.dtype, sh.Dh), lk = attn_dkv_lds_bytes(sh.dtype, sh.Dh);
+#define BG_BWD_CASE(DH)                                                                                             \
+  case DH: {                                                                                                        \
+    set_lds_limit(branch_attn_bwd_dq_kernel<T, DH>, lq);                                                            \
+    hipLaunchKernelGGL((branch_attn_bwd_dq_kernel<T, DH>), grid_q, block, lq, st, a);                               \
+    if (sh.S_text > 0) {                                                                                            \
+      if constexpr (DH <= 128) {                                                                                    \
+        set_lds_limit(branch_attn_bwd_dkv_kernel<T, DH, 0, DH / 32>, lk);                                           \
+        hipLaunchKernelGGL((branch_attn_bwd_dkv_kernel<T, DH, 0, DH / 32>), grid_k, block, lk, st, a);              \
+      } else {                                                                                                      \
+        set_lds_limit(branch_attn_bwd_dkv_kernel<T, DH, 0, DH / 64>, lk);                                           \
+        set_lds_limit(branch_attn_bwd_dkv_kernel<T, DH, DH / 64, DH / 32>, lk);                                     \
+        hipLaunchKernelGGL((branch_attn_bwd_dkv_kernel<T, DH, 0, DH / 64>), grid_k, block, lk, st, a);              \
+        hipLaunchKernelGGL((branch_attn_bwd_dkv_kernel<T, DH, DH / 64, DH / 32>), grid_k, block, lk, st, a);        \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (sh.n_slots > 0) hipLaunchKernelGGL((branch_attn_bwd_slots_kernel<T, DH>), grid_s, block, 0, st, a);         \
+  } break;
+  switch (sh.Dh) {
+    BG_BWD_CASE(32)
+    BG_BWD_CASE(64)
+    BG_BWD_CASE(128)
+    BG_BWD_CASE(256)
+  }
+#undef BG_BWD_CASE
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, const void* k_text, const void* v_text,
+                                  const void* const* k_slots, const void* const* v_slots, const int32_t* ctx_len,
+                                  const int32_t* path, const int32_t* path_len, const void* out, const float* lse,
+                                  const void* dout, void* dq, void* dk_text, void* dv_text, void* const* dk_slots,
+                                  void* const* dv_slots, float* delta, void* stream) {
+  const char* who = "bg_branch_attn_bwd";
+  if (int e = validate_attn_shape(shape, who)) return e;
+  if (int e = check_aligned16(q, who, "q")) return e;
+  if (int e = check_aligned16(out, who, "out")) return e;
+  if (int e = check_aligned16(dout, who, "dout")) return e;
+  if (int e = check_aligned16(dq, who, "dq")) return e;
+  BG_REQUIRE(lse && ctx_len && delta, "%s: null lse/ctx_len/delta", who);
+  if (shape->S_text > 0) {
+    if (int e = check_aligned16(k_text, who, "k_text")) return e;
+    if (int e = check_aligned16(v_text, who, "v_text")) return e;
+    if (int e = check_aligned16(dk_text, who, "dk_text")) return e;
+    if (int e = check_aligned16(dv_text, who, "dv_text")) return e;
+  }
+  BG_REQUIRE(shape->max_path == 0 || (path && path_len), "%s: null path/path_len", who);
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sh = *shape;
+  a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
+  a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse); a.dout = dout;
+  a.dq = dq; a.dk_text = dk_text; a.dv_text = dv_text; a.delta = delta;
+  for (int i = 0; i < shape->n_slots; ++i) {
+    if (int e = check_aligned16(k_slots[i], who, "k_slots[i]")) return e;
+    if (int e = check_aligned16(v_slots[i], who, "v_slots[i]")) return e;
+    if (int e = check_aligned16(dk_slots[i], who, "dk_slots[i]")) return e;
+    if (int e = check_aligned16(dv_slots[i], who, "dv_slots[i]")) return e;
+    a.k_slots[i] = k_slots[i]; a.v_slots[i] = v_slots[i];
+    a.dk_slots[i] = dk_slots[i]; a.dv_slots[i] = dv_slots[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (shape->dtype == BG_F32) launch_bwd<float>(a, st);
+  else launch_bwd<bf16_t>(a, st);
+  BG_CHECK_LAUNCH(who);
+  return BG_OK;
+}

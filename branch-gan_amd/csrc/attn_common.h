@@ -1,0 +1,285 @@
+// Shared pieces of the branch-attention kernels (forward, dQ, dK/dV).
+//
+// MFMA shapes (gfx950): bf16 inputs use v_mfma_f32_32x32x16_bf16, fp32 inputs use v_mfma_f32_32x32x2_f32
+// (exact fp32 FMA chain, so the fp32 path matches the reference's fp32 matmuls to rounding order).
+// Both give a 32x32 fp32 tile whose COLUMN is the lane (lane & 31) and whose 16 registers are the rows
+//   row(reg, half) = (reg & 3) + 8 * (reg >> 2) + 4 * half,      half = lane >> 5.
+// Operand maps:   bf16: A[row = lane&31][k = 8*half + j], B[k = 8*half + j][col = lane&31]   (j = 0..7)
+//                 fp32: A[row = lane&31][k = half],         B[k = half][col = lane&31]
+// A score tile is reused directly as the B operand of the next product (no LDS round trip): as bf16,
+// registers 8s..8s+7 form k-step s and element j of half h is row 16s + 8(j>>2) + 4h + (j&3); as fp32,
+// register r is one k-step whose half h is row (r&3) + 8(r>>2) + 4h.  The other operand is gathered
+// from LDS in exactly that row order.
+#pragma once
+#include "common.h"
+
+namespace bg {
+
+constexpr int ATT_WAVES = 4;   // waves per workgroup
+constexpr int ATT_TILE = 32;   // rows (queries or keys) per wave tile, keys per LDS tile
+
+struct AttnArgs {
+  bg_attn_shape sh;
+  const void* q;
+  const void* k_text;
+  const void* v_text;
+  const void* k_slots[BG_MAX_SLOTS];
+  const void* v_slots[BG_MAX_SLOTS];
+  const int32_t* ctx_len;
+  const int32_t* path;
+  const int32_t* path_len;
+  void* out;        // fwd: out;  bwd: forward output (for delta)
+  float* lse;
+  // backward only
+  const void* dout;
+  void* dq;
+  void* dk_text;
+  void* dv_text;
+  void* dk_slots[BG_MAX_SLOTS];
+  void* dv_slots[BG_MAX_SLOTS];
+  float* delta;
+};
+
+template <typename K>
+static inline void set_lds_limit(K kernel, size_t lds) {
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+__device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// LDS layouts ---------------------------------------------------------------------------------------
+// "row" layout  R[rows][DH + RPAD]: A operand of a product that reduces over d (scores).
+// "col" layout  bf16: C[DH][32 + 4] (transposed at staging);  fp32: the padded row layout serves both.
+template <typename T, int DH> struct Lds;
+template <int DH> struct Lds<float, DH> {
+  static constexpr int RSTRIDE = DH + 1;          // odd stride: conflict-free ds_read_b32 down a column
+  static constexpr int ROW_ELEMS = ATT_TILE * RSTRIDE;
+  static constexpr int COL_ELEMS = 0;             // not needed
+};
+template <int DH> struct Lds<bf16_t, DH> {
+  static constexpr int RSTRIDE = DH + 8;          // 16-byte pad: conflict-free ds_read_b128 down a column
+  static constexpr int ROW_ELEMS = ATT_TILE * RSTRIDE;
+  static constexpr int CSTRIDE = ATT_TILE + 4;    // 72-byte rows: 8-byte aligned key quads
+  static constexpr int COL_ELEMS = DH * CSTRIDE;
+};
+
+// Cooperative staging of a 32-row tile (rows row0 .. row0+31 of a [rows][DH] global matrix with element
+// stride `rs` between rows) by `nthreads` threads.  Rows >= nrows are zero-filled.
+template <typename T, int DH, bool ROW, bool COL>
+__device__ __forceinline__ void stage_tile(const T* g, int64_t rs, int row0, int nrows, T* lds_row, T* lds_col, int tid, int nthreads) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int CHUNKS = ATT_TILE * DH / VEC;
+  for (int c = tid; c < CHUNKS; c += nthreads) {
+    const int r = c / (DH / VEC), d0 = (c % (DH / VEC)) * VEC;
+    T v[VEC];
+    if (row0 + r < nrows) {
+      if constexpr (sizeof(T) == 4) {
+        f32x4 raw = *(const f32x4*)(g + (int64_t)(row0 + r) * rs + d0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = raw[j];
+      } else {
+        bf16x8 raw = *(const bf16x8*)(g + (int64_t)(row0 + r) * rs + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (T)0.0f;
+    }
+    if constexpr (sizeof(T) == 4) {
+      if constexpr (ROW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_row[r * Lds<T, DH>::RSTRIDE + d0 + j] = v[j];
+      }
+    } else {
+      if constexpr (ROW) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = v[j];
+        *(bf16x8*)(lds_row + r * Lds<T, DH>::RSTRIDE + d0) = o;
+      }
+      if constexpr (COL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_col[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = v[j];
+      }
+    }
+  }
+}
+
+// acc[32 x 32] += X_tile(rows r, reduce over d) * Y^T  where X comes from LDS "row" layout (A operand,
+// tile row on the lane) and Y's fragment for this lane's column is supplied by `yfrag(t)`.
+// bf16: yfrag(t) -> bf16x8 = Y[col][16t + 8h .. +8];  fp32: yfrag(t) -> float = Y[col][2t + h].
+template <typename T, int DH, typename YF>
+__device__ __forceinline__ void mma_reduce_d(f32x16& acc, const T* lds_row, int lane, YF yfrag) {
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int t = 0; t < DH / 2; ++t) {
+      const float a = lds_row[r * Lds<T, DH>::RSTRIDE + 2 * t + h];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, yfrag(t), acc, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < DH / 16; ++t) {
+      const bf16x8 a = *(const bf16x8*)(lds_row + r * Lds<T, DH>::RSTRIDE + 16 * t + 8 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, yfrag(t), acc, 0, 0, 0);
+    }
+  }
+}
+
+// out[dt][32 d x 32 cols] += Z^T (d x tile rows) * W (tile rows x cols), W = a score-shaped tile held in
+// registers `w` (column on the lane), Z = the LDS tile (bf16: "col" layout, fp32: padded "row" layout).
+template <typename T, int DH, int DT0, int DT1>
+__device__ __forceinline__ void mma_reduce_rows(f32x16 (&out)[DH / 32], const f32x16& w, const T* lds_z, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = tile_row(reg, h);
+#pragma unroll
+      for (int dt = DT0; dt < DT1; ++dt) {
+        const float a = lds_z[row * Lds<T, DH>::RSTRIDE + dt * 32 + r];
+        out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[reg], out[dt], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = (bf16_t)w[8 * s + j];
+#pragma unroll
+      for (int dt = DT0; dt < DT1; ++dt) {
+        const bf16_t* zr = lds_z + (dt * 32 + r) * Lds<bf16_t, DH>::CSTRIDE + 16 * s + 4 * h;
+        const bf16x4 lo = *(const bf16x4*)(zr);
+        const bf16x4 hi = *(const bf16x4*)(zr + 8);
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+        out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out[dt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Per-lane fragments of this lane's own row (query / key) for the B operand of mma_reduce_d.
+template <typename T, int DH> struct RowFrag;
+template <int DH> struct RowFrag<float, DH> {
+  static constexpr bool IN_REGS = (DH <= 64);
+  float v[IN_REGS ? DH / 2 : 1];
+  const float* p;
+  __device__ __forceinline__ void load(const float* row, bool valid, int h) {
+    p = valid ? row : nullptr;
+    if constexpr (IN_REGS) {
+#pragma unroll
+      for (int t = 0; t < DH / 2; ++t) v[t] = valid ? row[2 * t + h] : 0.f;
+    }
+  }
+  __device__ __forceinline__ float get(int t, int h) const {
+    if constexpr (IN_REGS) return v[t];
+    else return p ? p[2 * t + h] : 0.f;
+  }
+};
+template <int DH> struct RowFrag<bf16_t, DH> {
+  static constexpr bool IN_REGS = (DH <= 128);
+  bf16x8 v[IN_REGS ? DH / 16 : 1];
+  const bf16_t* p;
+  __device__ __forceinline__ void load(const bf16_t* row, bool valid, int h) {
+    p = valid ? row : nullptr;
+    if constexpr (IN_REGS) {
+#pragma unroll
+      for (int t = 0; t < DH / 16; ++t) {
+        if (valid) v[t] = *(const bf16x8*)(row + 16 * t + 8 * h);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[t][j] = (bf16_t)0.0f;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ bf16x8 get(int t, int h) const {
+    if constexpr (IN_REGS) return v[t];
+    else {
+      bf16x8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.0f;
+      return p ? *(const bf16x8*)(p + 16 * t + 8 * h) : z;
+    }
+  }
+};
+
+// Dot product of two DH-vectors split over a lane pair (l, l^32): half h covers [h*DH/2, (h+1)*DH/2).
+template <typename T, int DH>
+__device__ __forceinline__ float pair_dot(const T* a, const T* b, int h, bool valid) {
+  float acc = 0.f;
+  if (valid) {
+    constexpr int VEC = 16 / sizeof(T);
+    const T* pa = a + h * (DH / 2);
+    const T* pb = b + h * (DH / 2);
+#pragma unroll
+    for (int c = 0; c < DH / 2 / VEC; ++c) {
+      if constexpr (sizeof(T) == 4) {
+        f32x4 x = *(const f32x4*)(pa + 4 * c), y = *(const f32x4*)(pb + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fmaf(x[j], y[j], acc);
+      } else {
+        bf16x8 x = *(const bf16x8*)(pa + 8 * c), y = *(const bf16x8*)(pb + 8 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)x[j], (float)y[j], acc);
+      }
+    }
+  }
+  return acc + __shfl_xor(acc, 32);
+}
+
+// acc[dt][reg] += w * row[d(dt, reg, h)] : adds a scaled DH-vector (this lane's own row in global memory)
+// to an accumulator set whose rows are d (the layout of out[] in mma_reduce_rows).
+template <typename T, int DH>
+__device__ __forceinline__ void axpy_rowvec(f32x16 (&acc)[DH / 32], float w, const T* row, int h, bool valid) {
+  if (!valid) return;
+#pragma unroll
+  for (int dt = 0; dt < DH / 32; ++dt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const T* p = row + dt * 32 + 8 * g + 4 * h;
+      float x[4];
+      if constexpr (sizeof(T) == 4) {
+        f32x4 raw = *(const f32x4*)p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = raw[j];
+      } else {
+        bf16x4 raw = *(const bf16x4*)p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (float)raw[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[dt][4 * g + j] = fmaf(w, x[j], acc[dt][4 * g + j]);
+    }
+  }
+}
+
+// Stores an accumulator set (rows = d, column = this lane's row) to this lane's row in global memory.
+template <typename T, int DH>
+__device__ __forceinline__ void store_rowvec(const f32x16 (&acc)[DH / 32], float mul, T* row, int h, bool valid) {
+  if (!valid) return;
+#pragma unroll
+  for (int dt = 0; dt < DH / 32; ++dt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      T* p = row + dt * 32 + 8 * g + 4 * h;
+      if constexpr (sizeof(T) == 4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = acc[dt][4 * g + j] * mul;
+        *(f32x4*)p = o;
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(acc[dt][4 * g + j] * mul);
+        *(bf16x4*)p = o;
+      }
+    }
+  }
+}
+
+}  // namespace bg

@@ -1,0 +1,208 @@
+// Branch ("non-residual") attention forward — one MFMA kernel, arithmetic mask, online softmax.
+//
+// Replaces Models/NeoXBranchAttention/NeoXNonResidualAttention.py:183-232, Models/GPT2BranchAttention/
+// NonResidualAttention.py:119-172, the mask tensors of BranchPredictions/MultiStepPrediction.py:92-127 and
+// the KV concatenation of :129-152.  See include/branchgan.h: bg_branch_attn_fwd.
+//
+// Work split: grid = (ceil(NQ*K / 128), B*H); a workgroup = 4 waves, each wave owns 32 query rows and
+// keeps them "on the lane": S^T = K·Q^T puts one query per lane column, so the running max/sum and the
+// output rescale are per-lane scalars, and P^T feeds O^T = V^T·P^T straight from the accumulators.
+// Text K/V tiles (32 keys) are staged once per workgroup in LDS and shared by the 4 waves; tiles beyond
+// the workgroup's largest ctx_len are skipped (sparseIndex is sorted, so a tile of consecutive k has a
+// tight bound).  Branch keys (ancestors + self: the same branch point k of each slot on the node's path)
+// are this lane's own rows, so they are handled as per-lane dot products folded into the same online
+// softmax — no 32x wasted diagonal tiles.
+#include "attn_common.h"
+
+namespace bg {
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
+  using L = Lds<T, DH>;
+  constexpr int NDT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* k_row = (T*)smem;                              // K tile, "row" layout
+  T* v_z = k_row + L::ROW_ELEMS;                    // V tile: bf16 "col" layout, fp32 padded "row" layout
+  int* red = (int*)(v_z + (sizeof(T) == 4 ? L::ROW_ELEMS : L::COL_ELEMS));
+
+  const bg_attn_shape& sh = a.sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int R = sh.NQ * sh.K;
+  const int rq = blockIdx.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
+  const bool valid = rq < R;
+  const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
+  int ctx = valid ? a.ctx_len[kq] : 0;
+  ctx = min(ctx, sh.S_text);
+
+  const T* q_row = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)kq * sh.q_sk;
+  const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+
+  RowFrag<T, DH> qf;
+  qf.load(q_row, valid, h);
+
+  // workgroup / wave bounds on the text range
+  int wave_ctx = ctx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wave_ctx = max(wave_ctx, __shfl_xor(wave_ctx, o));
+  if (lane == 0) red[wave] = wave_ctx;
+  __syncthreads();
+  const int block_ctx = max(max(red[0], red[1]), max(red[2], red[3]));
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
+    __syncthreads();  // previous tile fully consumed
+    stage_tile<T, DH, true, false>(kt, sh.t_ss, kb, sh.S_text, k_row, nullptr, tid, 256);
+    if constexpr (sizeof(T) == 4) stage_tile<T, DH, true, false>(vt, sh.t_ss, kb, sh.S_text, v_z, nullptr, tid, 256);
+    else stage_tile<T, DH, false, true>(vt, sh.t_ss, kb, sh.S_text, nullptr, v_z, tid, 256);
+    __syncthreads();
+    if (kb >= wave_ctx) continue;  // wave-uniform
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    mma_reduce_d<T, DH>(s, k_row, lane, [&](int t) { return qf.get(t, h); });
+
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb + tile_row(r, h);
+      s[r] = (key < ctx) ? s[r] * sh.scale : -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);  // m = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __expf(s[r] - m_use);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+  }
+
+  // branch keys: the same branch point kq of every slot on this node's path (ancestors, then self)
+  const int plen = valid ? a.path_len[n] : 0;
+  for (int p = 0; p < sh.max_path; ++p) {
+    const bool act = p < plen;
+    int slot = act ? a.path[n * sh.max_path + p] : 0;
+    const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
+    // k_slots[] lives in the kernel argument buffer: index it with a wave-uniform value where possible
+    const T* kr = nullptr;
+    const T* vr = nullptr;
+    for (int sidx = 0; sidx < sh.n_slots; ++sidx) {
+      if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
+    }
+    const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
+    if (act) {
+      const float m_new = fmaxf(m, sc);
+      const float alpha = __expf(m - m_new);
+      const float pw = __expf(sc - m_new);
+      l = l * alpha + pw;
+      m = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      axpy_rowvec<T, DH>(o, pw, vr, h, true);
+    }
+  }
+
+  T* o_row = (T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)kq * sh.o_sk;
+  const float inv = (l > 0.f) ? 1.f / l : 0.f;
+  store_rowvec<T, DH>(o, inv, o_row, h, valid);
+  if (valid && h == 0) a.lse[((int64_t)bh * sh.NQ + n) * sh.K + kq] = (l > 0.f) ? m + logf(l) : -INFINITY;
+}
+
+size_t attn_fwd_lds_bytes(int dtype, int Dh) {
+  if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
+  return (size_t)(ATT_TILE * (Dh + 8) + Dh * (ATT_TILE + 4)) * 2 + 64;
+}
+
+int validate_attn_shape(const bg_attn_shape* s, const char* who) {
+  BG_REQUIRE(s, "%s: null shape", who);
+  BG_REQUIRE(s->dtype == BG_F32 || s->dtype == BG_BF16, "%s: dtype %d", who, s->dtype);
+  BG_REQUIRE(s->Dh == 32 || s->Dh == 64 || s->Dh == 128 || s->Dh == 256, "%s: Dh=%d not in {32,64,128,256}", who, s->Dh);
+  BG_REQUIRE(s->B > 0 && s->H > 0 && s->NQ > 0 && s->K > 0 && s->S_text >= 0, "%s: B=%d H=%d NQ=%d K=%d S=%d", who, s->B, s->H, s->NQ, s->K, s->S_text);
+  BG_REQUIRE((int64_t)s->B * s->H < 65536, "%s: B*H=%lld exceeds grid.y", who, (long long)s->B * s->H);
+  BG_REQUIRE(s->n_slots >= 0 && s->n_slots <= BG_MAX_SLOTS, "%s: n_slots=%d (max %d)", who, s->n_slots, BG_MAX_SLOTS);
+  BG_REQUIRE(s->max_path >= 0 && s->max_path <= BG_MAX_SLOTS, "%s: max_path=%d", who, s->max_path);
+  BG_REQUIRE(s->max_path == 0 || s->n_slots > 0, "%s: path entries but no slots", who);
+  const int64_t al = (s->dtype == BG_F32) ? 4 : 8;  // elements per 16 bytes
+  const int64_t st[] = {s->q_sb, s->q_sh, s->q_sn, s->q_sk, s->o_sb, s->o_sh, s->o_sn, s->o_sk, s->t_sb, s->t_sh, s->t_ss, s->s_sb, s->s_sh, s->s_sk};
+  for (int64_t v : st) BG_REQUIRE(v >= 0 && v % al == 0, "%s: stride %lld is not a multiple of %lld elements (16 bytes)", who, (long long)v, (long long)al);
+  return BG_OK;
+}
+
+int check_aligned16(const void* p, const char* who, const char* name) {
+  BG_REQUIRE(p && (((uintptr_t)p) & 15) == 0, "%s: %s is null or not 16-byte aligned", who, name);
+  return BG_OK;
+}
+
+template <typename T>
+static int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  const bg_attn_shape& sh = a.sh;
+  dim3 grid((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H)), block(256);
+  const size_t lds = attn_fwd_lds_bytes(sh.dtype, sh.Dh);
+  switch (sh.Dh) {
+    case 32: hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 32>), grid, block, lds, st, a); break;
+    case 64: hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 64>), grid, block, lds, st, a); break;
+    case 128: hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 128>), grid, block, lds, st, a); break;
+    default:
+      set_lds_limit(branch_attn_fwd_kernel<T, 256>, lds);
+      hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 256>), grid, block, lds, st, a);
+      break;
+  }
+  return BG_OK;
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_branch_attn_fwd(const bg_attn_shape* shape, const void* q, const void* k_text, const void* v_text,
+                                  const void* const* k_slots, const void* const* v_slots, const int32_t* ctx_len,
+                                  const int32_t* path, const int32_t* path_len, void* out, float* lse, void* stream) {
+  const char* who = "bg_branch_attn_fwd";
+  if (int e = validate_attn_shape(shape, who)) return e;
+  if (int e = check_aligned16(q, who, "q")) return e;
+  if (int e = check_aligned16(out, who, "out")) return e;
+  BG_REQUIRE(lse && ctx_len, "%s: null lse/ctx_len", who);
+  if (shape->S_text > 0) {
+    if (int e = check_aligned16(k_text, who, "k_text")) return e;
+    if (int e = check_aligned16(v_text, who, "v_text")) return e;
+  }
+  BG_REQUIRE(shape->max_path == 0 || (path && path_len), "%s: null path/path_len", who);
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sh = *shape;
+  a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
+  a.out = out; a.lse = lse;
+  for (int i = 0; i < shape->n_slots; ++i) {
+    if (int e = check_aligned16(k_slots[i], who, "k_slots[i]")) return e;
+    if (int e = check_aligned16(v_slots[i], who, "v_slots[i]")) return e;
+    a.k_slots[i] = k_slots[i];
+    a.v_slots[i] = v_slots[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (shape->dtype == BG_F32) launch_fwd<float>(a, st);
+  else launch_fwd<bf16_t>(a, st);
+  BG_CHECK_LAUNCH(who);
+  return BG_OK;
+}

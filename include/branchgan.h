@@ -1,0 +1,206 @@
+/* branchgan.h — C-ABI of libbranchgan_hip.so: the MI355X (gfx950) kernels behind Branch-GAN's
+ * branch-sequence hot path.
+ *
+ * The reference (FreddeFrallan/Branch-GAN) is pure Python on PyTorch and has no FFI layer; the entry
+ * points below are what a maintainer would bind (ctypes) to replace the chains of
+ * ATen ops cited beside each one.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - strides are in ELEMENTS of the tensor's dtype; the innermost (feature / vocabulary) dimension is
+ *     contiguous;
+ *   - dtype: BG_F32 (0) or BG_BF16 (1);  ids are int64 (the reference's type), lengths int32;
+ *   - `stream` is a hipStream_t (NULL = default stream); nothing here synchronises or allocates: the
+ *     caller owns every buffer, including the workspace whose size the *_workspace_bytes calls return;
+ *   - return value: 0 = ok, otherwise an error code; bg_last_error() gives the message (thread-local).
+ *     Shapes are validated on the host BEFORE any launch (a bad shape never reaches a kernel).
+ */
+#ifndef BRANCHGAN_H
+#define BRANCHGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_F32 0
+#define BG_BF16 1
+
+#define BG_OK 0
+#define BG_ERR_ARG 1      /* invalid argument / unsupported shape */
+#define BG_ERR_LAUNCH 2   /* HIP reported a launch error */
+#define BG_ERR_WORKSPACE 3
+
+#define BG_MAX_TOPN 64      /* samples per row */
+#define BG_MAX_BLOCKED 8    /* blocked ids per row */
+#define BG_MAX_SLOTS 64     /* branch KV slots (tree nodes incl. self) one call can see */
+
+const char* bg_last_error(void);
+int bg_version(void);
+/* gfx arch string of the current device ("gfx950"), into buf; returns BG_OK or BG_ERR_LAUNCH. */
+int bg_device_arch(char* buf, size_t buf_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling over the vocabulary.
+ * Replaces BranchPredictions/SamplingStrategies.py:197-205 (_topKSampling: full argsort, slice [:n]),
+ * :149-158 (_sampleWithoutReplacement: probs / noise, full argsort), :236-240 (inverse top-k) and the
+ * label blocking scatter+cat of :258-265, all in ONE pass over the row.
+ *
+ *   key[r][j] = (j in blocked[r] ? blocked_value : scores[r][j]) / noise[r][j]     (noise may be NULL)
+ *   out_ids[r][0..n) = the n largest keys, descending; equal keys in increasing j; NaN keys first
+ *   out_keys (optional) = those keys.
+ * The division is IEEE-correct fp32 (same bits as torch's probs / noise).
+ * row_map (optional, int64 (rows)): output row r reads input row row_map[r] of scores (noise is indexed
+ * by r): lets the caller sample only the K branch rows of a (B*S, V) tensor.
+ * workspace: bg_topn_workspace_bytes(rows, V, n) bytes (may be 0 -> workspace may be NULL).
+ */
+size_t bg_topn_workspace_bytes(int64_t rows, int64_t V, int n);
+int bg_topn_select(const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
+                   const int64_t* row_map,
+                   const float* noise, int64_t noise_row_stride,
+                   const int64_t* blocked, int n_blocked, float blocked_value,
+                   int n, int64_t* out_ids, float* out_keys,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Top-p filter + exponential race (SamplingStrategies.py:161-187, top_p_sampling):
+ * sort descending, cumulative sum, keep sorted position i iff cum[i+1] <= p (the reference's shift),
+ * renormalise by the kept mass, keys = kept / noise, n largest.  A row that keeps nothing yields NaN
+ * keys and therefore ids 0..n-1 (this library's tie rule).  probs fp32 only.
+ */
+size_t bg_topp_workspace_bytes(int64_t rows, int64_t V, int n);
+int bg_topp_select(const float* probs, int64_t rows, int64_t V, int64_t row_stride,
+                   const float* noise, int64_t noise_row_stride,
+                   const int64_t* blocked, int n_blocked,
+                   float top_p, int n, int64_t* out_ids, float* out_keys,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused softmax statistics over the vocabulary (never materialises probs).
+ * Replaces Models/Generator.py:47 (softmax over V), BranchPredictions/MultiStepPrediction.py:238-240,
+ * 257-261 (gathers of label / sampled-id probs) and Models/Losses/GeneratorLosses.py:133-137 (CE).
+ *   lse[r]            = log sum_j exp(logits[r][j])
+ *   out_logp[r][i]    = logits[r][ids[r][i]] - lse[r]         (ids[r][i] < 0 -> 0, no gradient)
+ * backward:  dlogits[r][j] = softmax[r][j] * (g_lse[r] - sum_i g_logp[r][i]) + sum_i g_logp[r][i]*[j == ids[r][i]]
+ * dlogits has the dtype and row stride of logits.
+ */
+int bg_softmax_stats_fwd(const void* logits, int dtype, int64_t rows, int64_t V, int64_t row_stride,
+                         const int64_t* ids, int n_ids,
+                         float* out_lse, float* out_logp, void* stream);
+int bg_softmax_stats_bwd(const void* logits, int dtype, int64_t rows, int64_t V, int64_t row_stride,
+                         const int64_t* ids, int n_ids, const float* lse,
+                         const float* g_lse, const float* g_logp,
+                         void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Branch ("non-residual") attention, forward and backward, with the mask computed arithmetically.
+ * Replaces Models/NeoXBranchAttention/NeoXNonResidualAttention.py:183-232 (_nonResidualTextAttention),
+ * Models/GPT2BranchAttention/NonResidualAttention.py:119-172 (nonResidualTextAttention), the mask tensors
+ * of BranchPredictions/MultiStepPrediction.py:92-127 and the KV concatenations of :129-152; with
+ * n_slots == 0 and ctx_len[i] = i + 1 it is also the root causal attention (NeoX :234-290, GPT-2 :78-117).
+ *
+ * Per batch b and head h there are NQ query nodes x K branch points.  Query (n, k) attends to
+ *   text keys   j < ctx_len[k]                         (ctx_len[k] = sparseIndex[k] + 1)
+ *   branch keys (slot s, k) for s in path[n][0 .. path_len[n])   (its ancestors and itself, same k only)
+ * softmax over that set with scores scale * <q, key>; out = sum w * value; lse = log-sum-exp (fp32).
+ *
+ * Layouts (element strides; feature dim Dh contiguous):
+ *   q, out, dout, dq : [b][h][n][k][Dh]  strides (q_sb, q_sh, q_sn, q_sk)
+ *   k_text, v_text   : [b][h][s][Dh]     strides (t_sb, t_sh, t_ss)         S_text rows
+ *   slots            : host arrays of n_slots device pointers, each [b][h][k][Dh] strides (s_sb, s_sh, s_sk)
+ *   ctx_len          : int32 [K];  path: int32 [NQ][max_path] slot indices;  path_len: int32 [NQ]
+ *   lse, delta       : fp32 [b][h][n][k] contiguous
+ * Dh in {32, 64, 128, 256}; n_slots <= BG_MAX_SLOTS.
+ * Backward writes dq, dk_text/dv_text (every text row, zeros where nothing attends) and each slot's
+ * dk/dv; gradients are plain stores (deterministic, no atomics), fp32 or bf16 like the inputs.
+ */
+typedef struct {
+  int dtype;
+  int B, H, NQ, K, Dh, S_text;
+  int n_slots, max_path;
+  float scale;
+  int64_t q_sb, q_sh, q_sn, q_sk;
+  int64_t o_sb, o_sh, o_sn, o_sk;     /* out / dout / dq share these */
+  int64_t t_sb, t_sh, t_ss;           /* k_text, v_text (and dk_text, dv_text) */
+  int64_t s_sb, s_sh, s_sk;           /* every slot tensor (and its gradient) */
+} bg_attn_shape;
+
+int bg_branch_attn_fwd(const bg_attn_shape* shape,
+                       const void* q, const void* k_text, const void* v_text,
+                       const void* const* k_slots, const void* const* v_slots,   /* host arrays */
+                       const int32_t* ctx_len, const int32_t* path, const int32_t* path_len,
+                       void* out, float* lse, void* stream);
+
+int bg_branch_attn_bwd(const bg_attn_shape* shape,
+                       const void* q, const void* k_text, const void* v_text,
+                       const void* const* k_slots, const void* const* v_slots,   /* host arrays */
+                       const int32_t* ctx_len, const int32_t* path, const int32_t* path_len,
+                       const void* out, const float* lse, const void* dout,
+                       void* dq, void* dk_text, void* dv_text,
+                       void* const* dk_slots, void* const* dv_slots,             /* host arrays */
+                       float* delta /* fp32 scratch [b][h][n][k] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NeoX prologue: split the fused QKV projection, move heads forward and apply partial rotary.
+ * Replaces NeoXNonResidualAttention.py:94-115 (view/permute/slices) and :425-432 (apply_rotary_pos_emb
+ * gathers).  qkv [B][T][H][3*Dh] contiguous -> q, k, v [B][H][T][Dh] contiguous; the first rot dims of
+ * q and k are rotated with cos/sin tables fp32 [max_pos][rot] at position_ids int32 [B][T].
+ * backward: dqkv from (dq, dk, dv).
+ */
+int bg_neox_qkv_rope_fwd(const void* qkv, int dtype, int B, int T, int H, int Dh, int rot,
+                         const float* cos_tab, const float* sin_tab, int max_pos, const int32_t* position_ids,
+                         void* q, void* k, void* v, void* stream);
+int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dtype, int B, int T, int H, int Dh, int rot,
+                         const float* cos_tab, const float* sin_tab, int max_pos, const int32_t* position_ids,
+                         void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused discriminator losses.  Replaces Models/Losses/DiscriminatorLoss.py:4-74 (≈60 ATen launches).
+ *   input_scores fp32 [B][S]; alt_scores fp32 [B][N][K] (the K real columns; the reference's zero padding
+ *   to S is implicit); depth_mask fp32 [N][K]; txt_in, txt_alt fp32 [B][S]; alt_alt fp32 [N][B][K];
+ *   root_links int32 [n_root]; child int32 [N][max_child] (-1 padded) with n_child int32 [N].
+ *   n_update = min(numNegativeUpdateSamples, N).
+ * out_losses fp32 [5] = {inputLoss, alterationLoss, valueHeadInputLoss, valueHeadAltLoss, valueHeadLoss}.
+ * backward: given g_losses fp32 [3] = d(total)/d{inputLoss, alterationLoss, valueHeadLoss}, writes the
+ * gradients of input_scores, alt_scores, txt_in, txt_alt, alt_alt (same shapes).
+ */
+typedef struct {
+  int B, S, N, K, n_update, n_root, max_child;
+} bg_disc_loss_shape;
+int bg_disc_loss_fwd(const bg_disc_loss_shape* shape, const float* input_scores, const float* alt_scores,
+                     const float* depth_mask, const float* txt_in, const float* txt_alt, const float* alt_alt,
+                     const int32_t* root_links, const int32_t* child, const int32_t* n_child,
+                     float* out_losses, void* stream);
+int bg_disc_loss_bwd(const bg_disc_loss_shape* shape, const float* input_scores, const float* alt_scores,
+                     const float* depth_mask, const float* txt_in, const float* txt_alt, const float* alt_alt,
+                     const int32_t* root_links, const int32_t* child, const int32_t* n_child,
+                     const float* g_losses,
+                     float* d_input_scores, float* d_alt_scores, float* d_txt_in, float* d_txt_alt, float* d_alt_alt,
+                     void* stream);
+
+/* Fused generator REINFORCE loss.  Replaces Models/Losses/AdvantageCalculations.py:5-46,
+ * ReinforceLoss.py:21-52 and GeneratorLosses.py:84-131.
+ *   input_scores fp32 [B][S] (already replaced by ones when teacher forcing); alt_scores fp32 [B][N][K];
+ *   in_head, alt_head fp32 [B][S] (text value heads); label_logp fp32 [B][S-1] (log prob of the true next
+ *   token); alt_logp fp32 [B][N][K] (log prob of each sampled branch token); depth_mask fp32 [N][K].
+ * out fp32 [2] = {loss-RL-input, loss-RL-alterations}.  backward: g fp32 [2] -> d_label_logp, d_alt_logp.
+ * Probabilities enter as log-probs; the clamp to [1e-6, 1-1e-6] of ReinforceLoss.py:22,46 is applied to
+ * exp(logp) and its zero gradient outside the clamp is reproduced.
+ */
+typedef struct {
+  int B, S, N, K;
+  float wA, wB, wC;
+  int ignore_input, ignore_alt;   /* IncorrectValueHeadsPolicy.IGNORE_SAMPLE for input / alterations */
+  int use_depth_mask;             /* 0: reference's depthMask=None branch (mean over [:, :, :-1]) */
+} bg_rl_loss_shape;
+int bg_rl_loss_fwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
+                   const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
+                   const float* depth_mask, float* out_losses, void* stream);
+int bg_rl_loss_bwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
+                   const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
+                   const float* depth_mask, const float* g_losses,
+                   float* d_label_logp, float* d_alt_logp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRANCHGAN_H */

@@ -1,0 +1,177 @@
+"""GPU parity: bg_branch_attn_fwd/bwd (through the C-ABI) vs goldens captured from the reference's
+_nonResidualTextAttention / nonResidualTextAttention, vs the oracle at other shapes, and properties.
+
+Tolerances (stated, per BASELINE north_star):  fp32 inputs -> |err| <= 2e-5 (fp32 MFMA = exact fma chain; the
+differences are summation order and the hardware exp);  bf16 inputs -> |err| <= 3e-2 on O(1) values, checked
+against the oracle evaluated on the SAME bf16-rounded inputs in fp32."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _split_ctx(kctx, S, K, d):
+    text = kctx[:, :, :S]
+    anc = [kctx[:, :, S + j * K: S + (j + 1) * K] for j in range(d - 1)]
+    return text, anc
+
+
+def _scale(fam, Dh, inv, layer):
+    s = 1.0 / math.sqrt(Dh)
+    return s / (layer + 1) if (fam == A.GPT2 and inv) else s
+
+
+def _run(ops, q, k, v, kctx, vctx, sparse, S, K, d, scale, dtype=torch.float32):
+    dev = "cuda"
+    cast = lambda t: t.to(dtype).to(dev).requires_grad_(True)
+    kt, ka = _split_ctx(kctx, S, K, d)
+    vt, va = _split_ctx(vctx, S, K, d)
+    leaves = dict(q=cast(q), kt=cast(kt.contiguous()), vt=cast(vt.contiguous()),
+                  ks=[cast(t.contiguous()) for t in ka] + [cast(k)], vs=[cast(t.contiguous()) for t in va] + [cast(v)])
+    ctx_len = (torch.as_tensor(sparse) + 1).to(torch.int32).to(dev)
+    out, lse = ops.branch_attention(leaves["q"], leaves["kt"], leaves["vt"], ctx_len, leaves["ks"], leaves["vs"], scale=scale)
+    return out, lse, leaves
+
+
+def test_golden_forward_backward_fp32(golden):
+    from branchgan import ops
+    g = golden("g1_attention")
+    for ci, fam, H, Dh, K, S, depth, inv, layer in g["meta"].tolist():
+        fam = A.NEOX if fam == 0 else A.GPT2
+        if Dh < 32:
+            continue  # kernels take Dh in {32,64,128,256}; Dh=8 cases are covered by the oracle tests only
+        sparse = g[f"c{ci}_sparse"]
+        for d in range(1, depth + 1):
+            p = f"c{ci}_d{d}_"
+            t = {k: torch.from_numpy(g[p + k]) for k in ["q", "k", "v", "kctx", "vctx", "gout"]}
+            out, lse, leaves = _run(ops, t["q"], t["k"], t["v"], t["kctx"], t["vctx"], sparse, S, K, d, _scale(fam, Dh, inv, layer))
+            np.testing.assert_allclose(out.detach().cpu().numpy(), g[p + "out"], atol=2e-5, rtol=0, err_msg=p)
+            out.backward(t["gout"].cuda())
+            np.testing.assert_allclose(leaves["q"].grad.cpu().numpy(), g[p + "dq"], atol=2e-5, err_msg=p + "dq")
+            np.testing.assert_allclose(leaves["ks"][-1].grad.cpu().numpy(), g[p + "dk"], atol=2e-5, err_msg=p + "dk")
+            np.testing.assert_allclose(leaves["vs"][-1].grad.cpu().numpy(), g[p + "dv"], atol=2e-5, err_msg=p + "dv")
+            dkctx = torch.cat([leaves["kt"].grad] + [x.grad for x in leaves["ks"][:-1]], dim=2).cpu().numpy()
+            dvctx = torch.cat([leaves["vt"].grad] + [x.grad for x in leaves["vs"][:-1]], dim=2).cpu().numpy()
+            np.testing.assert_allclose(dkctx, g[p + "dkctx"], atol=2e-5, err_msg=p + "dkctx")
+            np.testing.assert_allclose(dvctx, g[p + "dvctx"], atol=2e-5, err_msg=p + "dvctx")
+            # lse vs the golden weights: weight of the self column = exp(score_self - lse)
+            w_self = g[p + "weights"][..., -1]
+            sc = (t["q"] * t["k"]).sum(-1).numpy() * _scale(fam, Dh, inv, layer)
+            np.testing.assert_allclose(np.exp(sc - lse.cpu().numpy()), w_self, atol=2e-5)
+
+
+CASES = [  # B, H, Dh, S, K, depth
+    (2, 3, 64, 256, 32, 4), (1, 2, 128, 130, 40, 2), (2, 2, 32, 70, 33, 3), (1, 1, 256, 96, 64, 2), (1, 12, 64, 512, 64, 8),
+]
+
+
+@pytest.mark.parametrize("B,H,Dh,S,K,depth", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vs_oracle(B, H, Dh, S, K, depth, dtype):
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(B * 1000 + Dh + S)
+    sparse = np.sort(np.random.RandomState(S).choice(S - 1, K, replace=False))
+    r = lambda *s: torch.randn(*s, generator=gen).to(dtype).float()      # oracle sees the same (rounded) values
+    q, k, v = r(B, H, K, Dh), r(B, H, K, Dh), r(B, H, K, Dh)
+    C = S + (depth - 1) * K
+    kctx, vctx, gout = r(B, H, C, Dh), r(B, H, C, Dh), r(B, H, K, Dh)
+    mask = A.tree_mask_from_descriptor(torch.as_tensor(sparse) + 1, depth - 1, S, K)
+    lv = [t.clone().requires_grad_(True) for t in (q, k, v, kctx, vctx)]
+    o_ref, w_ref = A.branch_attention(A.NEOX, *lv, mask=mask)
+    g_ref = torch.autograd.grad(o_ref, lv, gout)
+    out, lse, leaves = _run(ops, q, k, v, kctx, vctx, sparse, S, K, depth, 1.0 / math.sqrt(Dh), dtype)
+    out.backward(gout.to(dtype).cuda())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    f = lambda t: t.detach().float().cpu().numpy()
+    np.testing.assert_allclose(f(out), o_ref.detach().numpy(), atol=tol)
+    np.testing.assert_allclose(f(leaves["q"].grad), g_ref[0].numpy(), atol=tol)
+    np.testing.assert_allclose(f(leaves["ks"][-1].grad), g_ref[1].numpy(), atol=tol)
+    np.testing.assert_allclose(f(leaves["vs"][-1].grad), g_ref[2].numpy(), atol=tol)
+    dkctx = torch.cat([leaves["kt"].grad] + [x.grad for x in leaves["ks"][:-1]], dim=2)
+    dvctx = torch.cat([leaves["vt"].grad] + [x.grad for x in leaves["vs"][:-1]], dim=2)
+    np.testing.assert_allclose(f(dkctx), g_ref[3].numpy(), atol=tol * 4)   # text rows sum up to K query rows
+    np.testing.assert_allclose(f(dvctx), g_ref[4].numpy(), atol=tol * 4)
+    assert out.dtype == dtype and leaves["kt"].grad.dtype == dtype
+
+
+def test_multi_node_tree_one_pass_equals_node_by_node():
+    """One launch over all nodes of a branching tree (paths differ per node) == per-node launches; gradients of shared
+    slots accumulate over the nodes that see them."""
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(3)
+    B, H, Dh, S, K = 2, 2, 64, 50, 7
+    sparse = torch.tensor([0, 3, 10, 11, 30, 40, 48])
+    ctx_len = (sparse + 1).int().cuda()
+    paths = [[0], [0, 1], [2], [2, 3], [2, 4]]           # nodes: a, a1, b, b1, b2
+    N = len(paths)
+    mk = lambda *s: torch.randn(*s, generator=gen).cuda().requires_grad_(True)
+    q = mk(B, H, N, K, Dh)
+    kt, vt = mk(B, H, S, Dh), mk(B, H, S, Dh)
+    ks, vs = [mk(B, H, K, Dh) for _ in range(N)], [mk(B, H, K, Dh) for _ in range(N)]
+    gout = torch.randn(B, H, N, K, Dh, generator=gen).cuda()
+    out, _ = ops.branch_attention(q, kt, vt, ctx_len, ks, vs, paths=paths)
+    all_leaves = [q, kt, vt] + ks + vs
+    g_one = torch.autograd.grad(out, all_leaves, gout)
+    outs = []
+    for n, p in enumerate(paths):
+        o, _ = ops.branch_attention(q[:, :, n], kt, vt, ctx_len, [ks[i] for i in p], [vs[i] for i in p])
+        outs.append(o)
+    out2 = torch.stack(outs, dim=2)
+    g_two = torch.autograd.grad(out2, all_leaves, gout)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out2.detach().cpu().numpy(), atol=1e-6)
+    for a, b in zip(g_one, g_two):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5)
+    # and against the oracle for node b2 (path [2, 4]): ancestors = slot 2, self = slot 4
+    cpu = lambda t: t.detach().cpu()
+    mask = A.tree_mask_from_descriptor(sparse + 1, 1, S, K)
+    o_ref, _ = A.branch_attention(A.NEOX, cpu(q[:, :, 4]), cpu(ks[4]), cpu(vs[4]), torch.cat((cpu(kt), cpu(ks[2])), 2),
+                                  torch.cat((cpu(vt), cpu(vs[2])), 2), mask=mask)
+    np.testing.assert_allclose(cpu(out[:, :, 4]).numpy(), o_ref.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("fam", [A.NEOX, A.GPT2])
+def test_root_causal_attention_matches_oracle(fam):
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(9)
+    B, H, S, Dh = 2, 3, 200, 64
+    q, k, v, go = [torch.randn(B, H, S, Dh, generator=gen) for _ in range(4)]
+    lv = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o_ref, _ = A.causal_attention(fam, *lv)
+    g_ref = torch.autograd.grad(o_ref, lv, go)
+    ld = [t.cuda().requires_grad_(True) for t in (q, k, v)]
+    o, _ = ops.causal_attention(*ld)
+    g = torch.autograd.grad(o, ld, go.cuda())
+    np.testing.assert_allclose(o.detach().cpu().numpy(), o_ref.detach().numpy(), atol=2e-5)
+    for a, b in zip(g, g_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=1e-4)
+
+
+def test_strided_views_of_fused_qkv():
+    """q/k/v passed as views of one (B, T, 3, H, Dh) projection output: no copies, same numbers."""
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(11)
+    B, H, K, Dh, S = 2, 4, 16, 64, 40
+    qkv = torch.randn(B, K, 3, H, Dh, generator=gen).cuda()
+    q, k, v = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]       # (B,H,K,Dh) views, last dim contiguous
+    kt, vt = torch.randn(B, H, S, Dh, generator=gen).cuda(), torch.randn(B, H, S, Dh, generator=gen).cuda()
+    ctx = torch.arange(3, 3 + 2 * K, 2).int().cuda()
+    o1, _ = ops.branch_attention(q, kt, vt, ctx, [k], [v])
+    o2, _ = ops.branch_attention(q.contiguous(), kt, vt, ctx, [k.contiguous()], [v.contiguous()])
+    assert torch.equal(o1, o2)
+
+
+def test_shape_errors():
+    from branchgan import ops
+    q = torch.randn(1, 1, 4, 48).cuda()                   # Dh = 48 unsupported
+    kt = torch.randn(1, 1, 8, 48).cuda()
+    with pytest.raises(RuntimeError):
+        ops.branch_attention(q, kt, kt, torch.ones(4, dtype=torch.int32).cuda(), [q], [q])
+    q = torch.randn(1, 1, 4, 64).cuda()
+    with pytest.raises(ValueError):
+        ops.branch_attention(q, torch.randn(1, 1, 8, 64).cuda(), torch.randn(1, 1, 8, 64).cuda(),
+                             torch.ones(5, dtype=torch.int32).cuda(), [q], [q])
