@@ -33,7 +33,7 @@ class DiscLossShape(ctypes.Structure):
 
 class RlLossShape(ctypes.Structure):
     _fields_ = [("B", c_i32), ("S", c_i32), ("N", c_i32), ("K", c_i32), ("wA", c_f32), ("wB", c_f32), ("wC", c_f32),
-                ("ignore_input", c_i32), ("ignore_alt", c_i32), ("use_depth_mask", c_i32)]
+                ("ignore_input", c_i32), ("ignore_alt", c_i32), ("use_depth_mask", c_i32), ("probs_input", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/branchgan.h declares

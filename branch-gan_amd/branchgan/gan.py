@@ -1,0 +1,102 @@
+"""One Branch-GAN step — host side.  Mirrors Models/GanSetup.py (reference): GannSetup, trainForwardPassNoMetrics and the
+loss-dict keys; the padding of branch tensors to S columns is never materialised (the kernels evaluate it)."""
+import math
+
+import torch
+
+from . import losses as Losses
+from . import tree as MultiStepPrediction
+from .configs import ReinforcementLearningConfig
+from .models import NonResidualDiscriminatorWithDualValueHeads, NonResidualGenerator, strip_reference_buffers
+
+
+class GannSetup(torch.nn.Module):
+    def __init__(self, generatorConfig, discriminatorConfig, mleLossWeight=1, rlLossWeight=1, discPredLossWeight=1,
+                 discValueHeadLossWeight=0.25, device='cuda', generatorDevice=None, discriminatorDevice=None,
+                 generatorTeacherForcingInput=True, samplingConf=None, **modelCreationConfigs):
+        super().__init__()
+        self.device = device
+        self.generatorDevice = generatorDevice if generatorDevice is not None else device
+        self.discriminatorDevice = discriminatorDevice if discriminatorDevice is not None else device
+        if str(self.generatorDevice) != str(self.discriminatorDevice):
+            raise NotImplementedError("generator/discriminator on two devices is out of scope (288 GB per MI355X; SURVEY §2 #13)")
+        self.generator = NonResidualGenerator(generatorConfig)
+        self.discriminator = NonResidualDiscriminatorWithDualValueHeads(discriminatorConfig)
+        self.generatorMleLossWeight, self.generatorRlLossWeight = mleLossWeight, rlLossWeight
+        self.discValueHeadLossWeight, self.discPredLossWeight = discValueHeadLossWeight, discPredLossWeight
+        self.samplingConf = samplingConf
+        self.generatorTeacherForcingInput = generatorTeacherForcingInput
+        self.noise_fn = None          # injection point for deterministic exponential noise (tests)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Loads a reference `GannSetup` / Generator.pt / Discriminator.pt state dict (same key names)."""
+        return super().load_state_dict(strip_reference_buffers(state_dict), strict=strict, assign=assign)
+
+    def createDiscAlterationLossWeights(self, inputIDs, alternationNodes, K):
+        """GanSetup.py:75-92 on the K real columns: 1 where sparseIndex + depth <= S - 1."""
+        pos = torch.stack([n.sparseIndex + n.depth for n in alternationNodes]).to(inputIDs.device)
+        return torch.less_equal(pos, inputIDs.shape[-1] - 1).float()
+
+    def _multiStepForwardPass(self, inputIDs, samplingConf, collectTreeDepthData=True):
+        sparseIndex = samplingConf.getSparseIndex(inputIDs, self.generatorDevice)
+        root, firstPred, probs, firstMaskedProbs = MultiStepPrediction.multiStepGenForward(
+            self.generator, inputIDs, samplingConf.rules, self.generatorDevice, sparseIndex=sparseIndex, clearTreePast=True,
+            noise_fn=self.noise_fn)
+        nodes = root.getSubNodes() if samplingConf.includeAllMultiStepSamplesForDisc else root.getLeaves()
+        if samplingConf.discDepthLossSchedule is not None or samplingConf.discpDepthLossWeight is not None:
+            raise NotImplementedError("depth loss schedules are undefined in the reference (quirk 14)")
+        K = nodes[0].ids.shape[1]
+        depthMask = self.createDiscAlterationLossWeights(inputIDs, nodes, K)                     # (N, K)
+        forwardData = {'TreeNodeInfo': [(n.depth, n.isRandom) for n in nodes]} if collectTreeDepthData else {}
+        forwardData['AlterationLogProbs'] = torch.stack([n.logProbs for n in nodes], dim=1)      # (B, N, K), autograd-connected
+        forwardData['LabelLogProbs'] = root.labelLogProbs
+        forwardData['NumBranchPoints'] = K
+        MultiStepPrediction.multiStepDiscForward(self.discriminator, root, self.discriminatorDevice, dualValueHeads=True,
+                                                 clearTreePast=False)
+        forwardData['DiscValueHeads'] = {
+            'txtInputPreds': root.valueHeadData['InputValue'], 'txtAlterationsPreds': root.valueHeadData['AlterationsValue'],
+            'altInputPreds': torch.stack([n.valueHeadData['InputValue'] for n in nodes], dim=0),
+            'altAlterationsPreds': torch.stack([n.valueHeadData['AlterationsValue'] for n in nodes], dim=0)}
+        forwardData['SubNodeStructure'] = MultiStepPrediction.getSubNodeListTreeStructure(root, nodes)
+        discInputPred = root.discPreds
+        discAlterationScores = torch.stack([n.discPreds.prediction for n in nodes], dim=1)       # (B, N, K)
+        MultiStepPrediction.clearTree(root, clearAll=True)
+        return inputIDs, (firstPred.logits, probs, firstMaskedProbs), (discInputPred, discAlterationScores, depthMask, None), forwardData
+
+    def forwardPass(self, inputIDs, samplingConf, **kwargs):
+        samplingConf = self.samplingConf if samplingConf is None else samplingConf
+        if kwargs.get('mixedPrecision', False):
+            raise NotImplementedError("fp16 autocast + GradScaler is replaced by a bf16 model dtype (SURVEY §2 #15)")
+        return self._multiStepForwardPass(inputIDs, samplingConf)
+
+    def _internalTrainForwardPass(self, inputIDs, samplingConf, numNegativeUpdateSamples=1, **kwargs):
+        samplingConf = self.samplingConf if samplingConf is None else samplingConf
+        inputIDs, genData, discData, fpd = self.forwardPass(inputIDs, samplingConf, **kwargs)
+        genLogits, genProbs, _ = genData
+        discInputPreds, discAlterationScores, depthMask, discDepthWeights = discData
+        K = fpd['NumBranchPoints']
+        discInputLoss, discAlterationLoss, info = Losses.calcDiscriminatorLoss(
+            self, discInputPreds.prediction, discAlterationScores, numNegativeUpdateSamples, depthMask, discDepthWeights,
+            collectTreeDepthData=kwargs.get('collectTreeDepthData', False), forwardPassData=fpd, numBranchPoints=K)
+        if samplingConf.separateInputAltLoss:
+            discPredLoss = (discInputLoss * samplingConf.inputLossWeight + discAlterationLoss) / 2
+        else:
+            n = info['numAlterationSamples']
+            discPredLoss = (discInputLoss * samplingConf.inputLossWeight + discAlterationLoss * n) / (n + 1)
+        discLoss = discPredLoss * self.discPredLossWeight + info['ValueHeadLoss'] * self.discValueHeadLossWeight
+        discLosses = {'loss': discLoss, 'predLoss': discPredLoss, 'loss-Input': discInputLoss, 'loss-Alterations': discAlterationLoss}
+        genLosses = Losses.calcGeneratorLoss(self, inputIDs, genLogits, genProbs, discInputPreds.prediction.detach(),
+                                             discAlterationScores.detach(), fpd,
+                                             reinforcementLearningConfig=kwargs.get('reinforcementLearningConfig') or ReinforcementLearningConfig(),
+                                             depthMask=depthMask)
+        discLosses.update(info)
+        if kwargs.get('checkNaN', True):                 # GanSetup.py:249-256 (one host sync per step instead of one per key)
+            bad = torch.isnan(torch.stack([v.detach().float() for v in genLosses.values() if isinstance(v, torch.Tensor)]))
+            if bool(bad.any()):
+                keys = [k for k, v in genLosses.items() if isinstance(v, torch.Tensor)]
+                raise Exception("Generator loss {} is NaN".format(keys[int(bad.float().argmax())]))
+        return discLosses, genLosses, genData, discData, fpd
+
+    def trainForwardPassNoMetrics(self, inputIDs, samplingConf, numNegativeUpdateSamples=1, **kwargs):
+        discLosses, genLosses, *_ = self._internalTrainForwardPass(inputIDs, samplingConf, numNegativeUpdateSamples, **kwargs)
+        return discLosses, genLosses

@@ -1,0 +1,534 @@
+"""The two LM families with branch ("non-residual") attention, generator and discriminator wrappers.
+
+Host-side mirror of Models/NeoXBranchAttention/*, Models/GPT2BranchAttention/*, Models/Generator.py and
+Models/Discriminator.py (reference): same class / method names, argument meaning and state-dict key names
+(SURVEY.md §8f-1), own implementation.  Dense GEMMs (QKV, projections, MLP, LM head) go through torch
+(hipBLASLt); attention (root causal AND branch), the NeoX QKV-split + rotary prologue and everything over the
+vocabulary run in the hand-written HIP kernels of libbranchgan_hip.so (branchgan.ops).  No CPU path.
+
+Branch mode is selected, like the reference, by passing `textualPast`.  Two forms are accepted:
+  * engine form: `textualPast` is a BranchPast (text KV + ancestor KV slots + arithmetic mask descriptor:
+    ctx_len and per-node slot paths) — no mask tensor, no KV concatenation;
+  * reference form: `textualPast` = per layer (k_ctx, v_ctx) concatenated as getFullPast builds them, plus
+    `customCasualMask` = the bool mask of PredictionTreeNode.getAttentionMask (validated to be that pattern and
+    converted to the descriptor; anything else raises NotImplementedError) or None (legacy default mask).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .configs import LMConfig
+
+_IGNORED_BUFFERS = (".attention.bias", ".attention.self_bias", ".attention.masked_bias", ".attn.bias", ".attn.self_bias",
+                    ".attn.masked_bias")
+
+
+class BranchPast:
+    """KV context + arithmetic mask of one branch forward over NQ query nodes x K branch points."""
+
+    def __init__(self, text, ancestors, ctx_len, paths, n_query_nodes=1):
+        self.text = text                    # per layer (k_text, v_text)  (B,H,S,Dh)
+        self.ancestors = ancestors          # per layer list of (k, v) slots (B,H,K,Dh), possibly empty
+        self.ctx_len = ctx_len              # int32 (K,) on the device: sparseIndex + 1
+        self.paths = paths                  # per query node: slot indices; i < n_anc -> ancestors[i], else own node i - n_anc
+        self.n_query_nodes = n_query_nodes
+
+    def layer(self, i):
+        return SimpleNamespace(text=self.text[i], ancestors=self.ancestors[i], ctx_len=self.ctx_len, paths=self.paths,
+                               n_query_nodes=self.n_query_nodes)
+
+
+def descriptor_from_bool_mask(mask, K, C):
+    """Reference mask (B,1,K,C+1) -> (ctx_len (K,) int32, n_anc).  Accepts exactly the T1 pattern
+    [text prefix | n_anc identity blocks | self column] (MultiStepPrediction.py:92-127), identical over the batch."""
+    if mask.dtype != torch.bool or mask.dim() != 4 or mask.shape[-2] != K or mask.shape[-1] != C + 1:
+        raise NotImplementedError("customCasualMask must be the bool (B,1,K,C+1) mask of PredictionTreeNode.getAttentionMask")
+    m = mask[0, 0].cpu()
+    if not bool((mask == mask[:1]).all()):
+        raise NotImplementedError("customCasualMask differs across the batch: not a branch-tree mask")
+    eye = torch.eye(K, dtype=torch.bool)
+    for n_anc in range(C // K, -1, -1):
+        S = C - n_anc * K
+        if S < 0:
+            continue
+        text, rest = m[:, :S], m[:, S:C]
+        ctx = text.sum(1)
+        prefix = torch.arange(S).unsqueeze(0) < ctx.unsqueeze(1)
+        if bool((text == prefix).all()) and bool((rest == eye.repeat(1, n_anc)).all()) and bool(m[:, -1].all()):
+            return ctx.to(torch.int32), n_anc
+    raise NotImplementedError("customCasualMask is not a branch-tree mask (text prefix | per-depth diagonals | self)")
+
+
+def _legacy_layer_past(layer_past, mask, K, device):
+    """(k_ctx, v_ctx) [+ bool mask] of the reference -> the layer view the attention modules consume."""
+    k_ctx, v_ctx = layer_past
+    C = k_ctx.shape[-2]
+    if mask is None:        # legacy single-step default mask (A3): row i sees text j <= i + (C - K) - 1
+        ctx, n_anc = torch.arange(C - K, C, dtype=torch.int32), 0
+    else:
+        ctx, n_anc = descriptor_from_bool_mask(mask, K, C)
+    S = C - n_anc * K
+    anc = [(k_ctx[:, :, S + j * K: S + (j + 1) * K], v_ctx[:, :, S + j * K: S + (j + 1) * K]) for j in range(n_anc)]
+    return SimpleNamespace(text=(k_ctx[:, :, :S], v_ctx[:, :, :S]), ancestors=anc, ctx_len=ctx.to(device),
+                           paths=[list(range(n_anc + 1))], n_query_nodes=1)
+
+
+def branch_attention_core(q, k, v, lp, scale):
+    """q, k, v (B,H,NQ*K,Dh) of the new tokens; lp = layer view of a BranchPast.  -> (B,H,NQ*K,Dh)."""
+    NQ = lp.n_query_nodes
+    K = q.shape[2] // NQ
+    q5 = q.unflatten(2, (NQ, K))
+    k5, v5 = k.unflatten(2, (NQ, K)), v.unflatten(2, (NQ, K))
+    slots_k = [a[0] for a in lp.ancestors] + [k5[:, :, n] for n in range(NQ)]
+    slots_v = [a[1] for a in lp.ancestors] + [v5[:, :, n] for n in range(NQ)]
+    out, _ = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, slots_k, slots_v, paths=lp.paths, scale=scale)
+    return out.flatten(2, 3)
+
+
+def dense_weights_from(q, k_self, k_ctx, mask, scale):
+    """Debug helper for output_attentions=True: the (B,H,K,C+1) weights the reference materialises."""
+    s = torch.cat((q @ k_ctx.transpose(-1, -2), (q * k_self).sum(-1, keepdim=True)), -1) * scale
+    return torch.softmax(s.masked_fill(~mask, float("-inf")), -1)
+
+
+def _check_no_attn_dropout(p):
+    if p:
+        raise NotImplementedError("attention-probability dropout is not available inside the fused attention kernel: "
+                                  "use attn_pdrop / attention_dropout = 0 (as every parity run does)")
+
+
+_rope_cache = {}
+
+
+def rope_tables(rot, max_pos, base, device):
+    """fp32 cos/sin tables (max_pos, rot) of GPTNeoXRotaryEmbedding (:343-364); kept out of the module's buffers so a
+    bf16 cast of the model never rounds them."""
+    key = (rot, max_pos, float(base), str(device))
+    hit = _rope_cache.get(key)
+    if hit is None:
+        inv_freq = 1.0 / (base ** (torch.arange(0, rot, 2).float() / rot))
+        emb = torch.cat([torch.einsum("i,j->ij", torch.arange(max_pos, dtype=inv_freq.dtype), inv_freq)] * 2, dim=-1)
+        hit = (emb.cos().contiguous().to(device), emb.sin().contiguous().to(device))
+        _rope_cache[key] = hit
+    return hit
+
+
+class Conv1D(nn.Module):
+    """GPT-2's Conv1D: y = x @ W + b with W stored (in, out) — the reference state-dict layout."""
+
+    def __init__(self, nf, nx):
+        super().__init__()
+        self.nf = nf
+        self.weight = nn.Parameter(torch.empty(nx, nf))
+        self.bias = nn.Parameter(torch.zeros(nf))
+
+    def forward(self, x):
+        return torch.addmm(self.bias, x.reshape(-1, x.size(-1)), self.weight).view(*x.shape[:-1], self.nf)
+
+
+# =================================================================================================
+# GPT-NeoX family
+# =================================================================================================
+class NeoXNonResidualAttention(nn.Module):
+    """Models/NeoXBranchAttention/NeoXNonResidualAttention.py:7-148."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.num_attention_heads = config.num_attention_heads
+        self.hidden_size = config.hidden_size
+        self.head_size = config.head_dim
+        self.rotary_ndims = config.rotary_ndims
+        _check_no_attn_dropout(config.attn_pdrop)
+        inv_freq = 1.0 / (config.rotary_emb_base ** (torch.arange(0, self.rotary_ndims, 2).float() / self.rotary_ndims))
+        self.rotary_emb = nn.Module()
+        self.rotary_emb.register_buffer("inv_freq", inv_freq)
+        self.norm_factor = math.sqrt(self.head_size)
+        self.query_key_value = nn.Linear(config.hidden_size, 3 * config.hidden_size)
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+
+    def _nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
+                                  customCasualMask=None, dropoutRate=None):
+        """Reference signature (:183-184); dropoutRate is accepted and ignored there too."""
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is not supported on the fused path")
+        lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
+        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor), None   # weights are never formed
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, head_mask=None, layer_past=None,
+                use_cache=False, output_attentions=False, isNonResidual=False, textualPast=None, customCasualMask=None):
+        if layer_past is not None or attention_mask is not None or head_mask is not None:
+            raise NotImplementedError("layer_past / attention_mask / head_mask are not on the branch hot path")
+        B, T, _ = hidden_states.shape
+        qkv = self.query_key_value(hidden_states)
+        cos, sin = rope_tables(self.rotary_ndims, self.config.max_position_embeddings, self.config.rotary_emb_base, qkv.device)
+        query, key, value = ops.neox_qkv_rope(qkv, cos, sin, position_ids, self.num_attention_heads, self.head_size,
+                                              self.rotary_ndims)
+        present = (key, value) if use_cache else None
+        scale = 1.0 / self.norm_factor
+        if isNonResidual:
+            lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
+            attn_output = branch_attention_core(query, key, value, lp, scale)
+        else:
+            attn_output, _ = ops.causal_attention(query, key, value, scale=scale)
+        attn_output = attn_output.permute(0, 2, 1, 3).reshape(B, T, self.hidden_size)
+        attn_output = self.dense(attn_output)
+        outputs = (attn_output, present)
+        if output_attentions:
+            outputs += (None,)          # the fused kernel never forms the weights
+        return outputs
+
+
+class GPTNeoXMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense_h_to_4h = nn.Linear(config.hidden_size, config.intermediate_size)
+        self.dense_4h_to_h = nn.Linear(config.intermediate_size, config.hidden_size)
+
+    def forward(self, x):
+        return self.dense_4h_to_h(F.gelu(self.dense_h_to_4h(x)))
+
+
+class GPTNeoXLayer(nn.Module):
+    """NeoXNonResidualBase.py:73-133."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.use_parallel_residual = config.use_parallel_residual
+        self.input_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.post_attention_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.attention = NeoXNonResidualAttention(config)
+        self.mlp = GPTNeoXMLP(config)
+        self.hidden_dropout = config.resid_pdrop
+
+    def forward(self, hidden_states, position_ids=None, use_cache=False, textualPast=None, isNonResidual=False,
+                customCasualMask=None):
+        attn_output, present = self.attention(self.input_layernorm(hidden_states), position_ids=position_ids, use_cache=use_cache,
+                                              textualPast=textualPast, isNonResidual=isNonResidual,
+                                              customCasualMask=customCasualMask)[:2]
+        drop = (lambda x: F.dropout(x, self.hidden_dropout, self.training)) if self.hidden_dropout else (lambda x: x)
+        attn_output = drop(attn_output)
+        if self.use_parallel_residual:
+            hidden_states = drop(self.mlp(self.post_attention_layernorm(hidden_states))) + attn_output + hidden_states
+        else:
+            attn_output = attn_output + hidden_states
+            hidden_states = drop(self.mlp(self.post_attention_layernorm(attn_output))) + attn_output
+        return hidden_states, present
+
+
+def strip_reference_buffers(state_dict):
+    """Reference checkpoints carry mask buffers (bias / self_bias / masked_bias) and, when saved from DDP,
+    a `module.` prefix (Models/FileManagement.py:5-7): neither has a counterpart here."""
+    out = {}
+    for k, v in state_dict.items():
+        if k.endswith(_IGNORED_BUFFERS):
+            continue
+        out[k.replace("module.", "")] = v
+    return out
+
+
+class _LMBase(nn.Module):
+    def _init_weights(self, std):
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, Conv1D)):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, mean=0.0, std=std)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Accepts reference checkpoints: drops their mask buffers (bias / self_bias / masked_bias)."""
+        return super().load_state_dict(strip_reference_buffers(state_dict), strict=strict, assign=assign)
+
+
+class GPTNeoXModel(_LMBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_in = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([GPTNeoXLayer(config) for _ in range(config.num_hidden_layers)])
+        self.final_layer_norm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+def _positions(position_ids, B, T, device, offset=0):
+    if position_ids is None:
+        return torch.arange(offset, offset + T, dtype=torch.int32, device=device).unsqueeze(0).expand(B, T)
+    return position_ids.view(-1, T).to(torch.int32)
+
+
+def _layer_past(textualPast, i):
+    return textualPast.layer(i) if isinstance(textualPast, BranchPast) else textualPast[i]
+
+
+class GPTNeoXForCausalLM(_LMBase):
+    """NeoXNonResidualBase.py:303-400: LM head `embed_out` or 1-unit `valueHead`, chosen by returnLmLogits."""
+
+    def __init__(self, config):
+        super().__init__()
+        config = LMConfig.from_any(config)
+        self.config = config
+        self.gpt_neox = GPTNeoXModel(config)
+        self.embed_out = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.valueHead = nn.Linear(config.hidden_size, 1, bias=False)
+        self._init_weights(config.initializer_range)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None, head_mask=None,
+                past_key_values=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, textualPast=None, returnLmLogits=False, dropoutRate=None, customCasualMask=None):
+        if any(x is not None for x in (attention_mask, inputs_embeds, head_mask, past_key_values, labels)):
+            raise NotImplementedError("attention_mask / inputs_embeds / head_mask / past_key_values / labels are off the hot path")
+        B, T = input_ids.shape
+        pos = _positions(position_ids, B, T, input_ids.device)
+        branch = textualPast is not None
+        x = self.gpt_neox.embed_in(input_ids)
+        hidden_dropout = self.config.resid_pdrop
+        if hidden_dropout:
+            x = F.dropout(x, hidden_dropout, self.training)
+        presents, all_hidden = [], []
+        for i, layer in enumerate(self.gpt_neox.layers):
+            if output_hidden_states:
+                all_hidden.append(x)
+            x, present = layer(x, position_ids=pos, use_cache=bool(use_cache), isNonResidual=branch,
+                               textualPast=_layer_past(textualPast, i) if branch else None, customCasualMask=customCasualMask)
+            presents.append(present)
+        x = self.gpt_neox.final_layer_norm(x)
+        if output_hidden_states:
+            all_hidden.append(x)
+        logits = self.embed_out(x) if returnLmLogits else self.valueHead(x)
+        return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,
+                               hidden_states=tuple(all_hidden) if output_hidden_states else None, attentions=None,
+                               last_hidden_state=x)
+
+
+# =================================================================================================
+# GPT-2 family
+# =================================================================================================
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+class GPT2NonResidualAttention(nn.Module):
+    """Models/GPT2BranchAttention/NonResidualAttention.py:22-281."""
+
+    def __init__(self, config, is_cross_attention=False, layer_idx=None):
+        super().__init__()
+        if is_cross_attention:
+            raise NotImplementedError("cross attention is not on the branch hot path")
+        self.config = config
+        self.embed_dim = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = config.head_dim
+        self.split_size = self.embed_dim
+        self.scale_attn_weights = config.scale_attn_weights
+        self.scale_attn_by_inverse_layer_idx = config.scale_attn_by_inverse_layer_idx
+        self.layer_idx = layer_idx
+        self.c_attn = Conv1D(3 * self.embed_dim, self.embed_dim)
+        self.c_proj = Conv1D(self.embed_dim, self.embed_dim)
+
+    def _scale(self):
+        s = 1.0 / math.sqrt(self.head_dim) if self.scale_attn_weights else 1.0
+        return s / float(self.layer_idx + 1) if self.scale_attn_by_inverse_layer_idx else s
+
+    def nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
+                                 customCasualMask=None, dropoutRate=None):
+        """Reference signature (:119-120)."""
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is not supported on the fused path")
+        _check_no_attn_dropout(dropoutRate if dropoutRate is not None else self.config.attn_pdrop)
+        lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
+        return branch_attention_core(query, key, value, lp, self._scale()), None
+
+    def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None, encoder_hidden_states=None,
+                encoder_attention_mask=None, use_cache=False, output_attentions=False, nonResidual=False,
+                nonResidualTextOnly=False, nonResdiaulPastOnly=False, promptPast=None, textualPast=None, promptMask=None,
+                customCasualMask=None, dropoutRate=None):
+        if nonResidual or nonResdiaulPastOnly or promptPast is not None or encoder_hidden_states is not None or \
+                layer_past is not None or attention_mask is not None or head_mask is not None:
+            raise NotImplementedError()      # the reference raises for `nonResidual` too (:265-266); prompt modes are out of scope
+        _check_no_attn_dropout(dropoutRate if dropoutRate is not None else self.config.attn_pdrop)
+        B, T, _ = hidden_states.shape
+        qkv = self.c_attn(hidden_states).view(B, T, 3, self.num_heads, self.head_dim)
+        query, key, value = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]     # strided views, no copies
+        present = (key, value) if use_cache else None
+        if nonResidualTextOnly:
+            lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
+            attn_output = branch_attention_core(query, key, value, lp, self._scale())
+        else:
+            attn_output, _ = ops.causal_attention(query, key, value, scale=self._scale())
+        attn_output = self.c_proj(attn_output.permute(0, 2, 1, 3).reshape(B, T, self.embed_dim))
+        p = dropoutRate if dropoutRate is not None else self.config.resid_pdrop
+        if p:
+            attn_output = F.dropout(attn_output, p)          # always-on like the reference (:274-275, quirk 1)
+        outputs = (attn_output, present)
+        if output_attentions:
+            outputs += (None,)
+        return outputs
+
+
+class GPT2MLP(nn.Module):
+    def __init__(self, inner, config):
+        super().__init__()
+        self.c_fc = Conv1D(inner, config.hidden_size)
+        self.c_proj = Conv1D(config.hidden_size, inner)
+        self.resid_pdrop = config.resid_pdrop
+
+    def forward(self, x):
+        x = self.c_proj(gelu_new(self.c_fc(x)))
+        return F.dropout(x, self.resid_pdrop, self.training) if self.resid_pdrop else x
+
+
+class NonResidualGPT2Block(nn.Module):
+    def __init__(self, config, layer_idx=None):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.attn = GPT2NonResidualAttention(config, layer_idx=layer_idx)
+        self.ln_2 = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.mlp = GPT2MLP(config.intermediate_size, config)
+
+    def forward(self, hidden_states, use_cache=False, nonResidualTextOnly=False, textualPast=None, customCasualMask=None,
+                dropoutRate=None):
+        a, present = self.attn(self.ln_1(hidden_states), use_cache=use_cache, nonResidualTextOnly=nonResidualTextOnly,
+                               textualPast=textualPast, customCasualMask=customCasualMask, dropoutRate=dropoutRate)[:2]
+        hidden_states = a + hidden_states
+        return hidden_states + self.mlp(self.ln_2(hidden_states)), present
+
+
+class NonResidualGPT2Model(_LMBase):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.wte = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.wpe = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.h = nn.ModuleList([NonResidualGPT2Block(config, layer_idx=i) for i in range(config.num_hidden_layers)])
+        self.ln_f = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class NonResidualGPT2LMHeadModel(_LMBase):
+    """NonResidualDiscriminatorBase.py:383-511."""
+
+    def __init__(self, config):
+        super().__init__()
+        config = LMConfig.from_any(config)
+        self.config = config
+        self.transformer = NonResidualGPT2Model(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.valueHead = nn.Linear(config.hidden_size, 1, bias=False)
+        self._init_weights(config.initializer_range)
+
+    def forward(self, input_ids=None, past_key_values=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                head_mask=None, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                customCasualMask=None, suffixOverrideEmbeddings=None, insertBlocks=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, promptPast=None, textualPast=None,
+                promptMask=None, returnLmLogits=False, dropoutRate=None):
+        if any(x is not None for x in (past_key_values, attention_mask, token_type_ids, head_mask, inputs_embeds, encoder_hidden_states,
+                                       encoder_attention_mask, suffixOverrideEmbeddings, insertBlocks, labels, promptPast, promptMask)):
+            raise NotImplementedError("prompt-past / cross-attention / adapter modes are off the branch hot path")
+        B, T = input_ids.shape
+        pos = _positions(position_ids, B, T, input_ids.device)
+        branch = textualPast is not None
+        tr = self.transformer
+        x = tr.wte(input_ids) + tr.wpe(pos.long())
+        p = dropoutRate if dropoutRate is not None else self.config.embd_pdrop
+        if p:
+            x = F.dropout(x, p)
+        presents, all_hidden = [], []
+        for i, block in enumerate(tr.h):
+            if output_hidden_states:
+                all_hidden.append(x)
+            x, present = block(x, use_cache=bool(use_cache), nonResidualTextOnly=branch,
+                               textualPast=_layer_past(textualPast, i) if branch else None, customCasualMask=customCasualMask,
+                               dropoutRate=dropoutRate)
+            presents.append(present)
+        x = tr.ln_f(x)
+        if output_hidden_states:
+            all_hidden.append(x)
+        logits = self.lm_head(x) if returnLmLogits else self.valueHead(x)
+        return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,
+                               hidden_states=tuple(all_hidden) if output_hidden_states else None, attentions=None,
+                               cross_attentions=None, last_hidden_state=x)
+
+
+def make_lm(config):
+    config = LMConfig.from_any(config)
+    return GPTNeoXForCausalLM(config) if config.model_type == "gpt_neox" else NonResidualGPT2LMHeadModel(config)
+
+
+# =================================================================================================
+# Generator / Discriminator wrappers
+# =================================================================================================
+class LazyProbs:
+    """softmax(logits) that is only formed if somebody asks (`.materialize()`); the hot path never does."""
+
+    def __init__(self, logits):
+        self.logits = logits
+        self.shape = logits.shape
+
+    def materialize(self):
+        return torch.softmax(self.logits, dim=-1)
+
+
+class GeneratorOutput:
+    def __init__(self, prediction=None, classProbs=None, discPreds=None, inputValuePreds=None, alterationsValuePreds=None):
+        self.prediction, self.classProbs, self.discPreds = prediction, classProbs, discPreds
+        self.inputValuePreds, self.alterationsValuePreds = inputValuePreds, alterationsValuePreds
+
+
+class NonResidualGenerator(nn.Module):
+    """Models/Generator.py:36-49; classProbs is lazy (the kernels work from the logits)."""
+
+    def __init__(self, generatorConfig):
+        super().__init__()
+        self.config = LMConfig.from_any(generatorConfig)
+        self.generator = make_lm(self.config)
+
+    def forward(self, args):
+        args = dict(args)
+        args['output_hidden_states'] = args.get('output_hidden_states', False)
+        prediction = self.generator(**args)
+        return GeneratorOutput(prediction, LazyProbs(prediction.logits))
+
+
+class DiscriminatorOutput:
+    def __init__(self, prediction=None, classProbs=None, transformerPred=None):
+        self.transformerPred, self.prediction, self.classProbs = transformerPred, prediction, classProbs
+
+
+class NonResidualDiscriminatorWithDualValueHeads(nn.Module):
+    """Models/Discriminator.py:15-127 (the tree path: doTransformerPassWithPrediction / doFinalizeSinglePrediction)."""
+
+    def __init__(self, discriminatorConfig):
+        super().__init__()
+        self.discriminatorConfig = LMConfig.from_any(discriminatorConfig)
+        self.nonResidualModel = make_lm(self.discriminatorConfig)
+        self.inputValueHead = nn.Linear(self.discriminatorConfig.hidden_size, 1)
+        self.alterationsValueHead = nn.Linear(self.discriminatorConfig.hidden_size, 1)
+        self.hasValueHeads = True
+
+    def _finalizeSinglePrediction(self, pred):
+        hidden = pred.hidden_states[-1] if pred.hidden_states is not None else pred.last_hidden_state
+        alterationsValuePreds = torch.sigmoid(self.alterationsValueHead(hidden))
+        inputValuePreds = torch.sigmoid(self.inputValueHead(hidden))
+        return torch.sigmoid(pred.logits.squeeze(-1)), inputValuePreds, alterationsValuePreds
+
+    def forward(self, inputArgs, doDiscForward=True, doTransformerPass=False, doFinalizeSinglePrediction=False,
+                doTransformerPassWithPrediction=False):
+        if doDiscForward:
+            raise NotImplementedError("the legacy single-step discForward is superseded by the tree path")
+        if doTransformerPass:
+            return self.nonResidualModel(**inputArgs)
+        if doTransformerPassWithPrediction:
+            transPred = self.nonResidualModel(**inputArgs)
+            return DiscriminatorOutput(torch.sigmoid(transPred.logits.squeeze(-1)), transformerPred=transPred)
+        if doFinalizeSinglePrediction:
+            return self._finalizeSinglePrediction(**inputArgs)
+
+
+NonResidualDiscriminator = NonResidualDiscriminatorWithDualValueHeads

@@ -262,3 +262,143 @@ def causal_attention(q, k, v, scale=None):
         _arange_cache[key] = ctx
     out, lse = branch_attention(q, k, v, ctx, (), (), paths=[[]], scale=scale)
     return out, lse
+
+
+# ---------------------------------------------------------------------------------------------------
+# NeoX prologue: split fused QKV, heads forward, partial rotary
+# ---------------------------------------------------------------------------------------------------
+class _NeoxQkvRope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, cos_tab, sin_tab, position_ids, H, Dh, rot):
+        C.require_cuda(qkv, cos_tab, sin_tab, position_ids)
+        qkv = qkv.contiguous()
+        B, T = qkv.shape[:2]
+        pos = position_ids.to(torch.int32).contiguous()
+        q, k, v = [torch.empty((B, H, T, Dh), dtype=qkv.dtype, device=qkv.device) for _ in range(3)]
+        C.check(C.lib().bg_neox_qkv_rope_fwd(C.ptr(qkv), C.dtype_code(qkv), B, T, H, Dh, rot, C.ptr(cos_tab), C.ptr(sin_tab),
+                                             cos_tab.shape[0], C.ptr(pos), C.ptr(q), C.ptr(k), C.ptr(v), C.stream_ptr()),
+                "bg_neox_qkv_rope_fwd")
+        ctx.save_for_backward(cos_tab, sin_tab, pos)
+        ctx.meta = (B, T, H, Dh, rot, qkv.dtype)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        cos_tab, sin_tab, pos = ctx.saved_tensors
+        B, T, H, Dh, rot, dtype = ctx.meta
+        zeros = lambda: torch.zeros((B, H, T, Dh), dtype=dtype, device=pos.device)
+        dq = dq.contiguous() if dq is not None else zeros()
+        dk = dk.contiguous() if dk is not None else zeros()
+        dv = dv.contiguous() if dv is not None else zeros()
+        dqkv = torch.empty((B, T, H * 3 * Dh), dtype=dtype, device=pos.device)
+        C.check(C.lib().bg_neox_qkv_rope_bwd(C.ptr(dq), C.ptr(dk), C.ptr(dv), C.dtype_code(dq), B, T, H, Dh, rot, C.ptr(cos_tab),
+                                             C.ptr(sin_tab), cos_tab.shape[0], C.ptr(pos), C.ptr(dqkv), C.stream_ptr()),
+                "bg_neox_qkv_rope_bwd")
+        return dqkv, None, None, None, None, None, None
+
+
+def neox_qkv_rope(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims):
+    """qkv (B,T,3*hidden) in the NeoX per-head interleaved order -> q, k (rotated), v, each (B,H,T,Dh)."""
+    return _NeoxQkvRope.apply(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused losses
+# ---------------------------------------------------------------------------------------------------
+_links_cache = {}
+
+
+def link_tables(root_links, alt_links, device):
+    key = (tuple(root_links), tuple(tuple(l) for l in alt_links), str(device))
+    hit = _links_cache.get(key)
+    if hit is None:
+        max_child = max(1, max((len(l) for l in alt_links), default=1))
+        child = torch.full((len(alt_links), max_child), -1, dtype=torch.int32)
+        for i, l in enumerate(alt_links):
+            if l:
+                child[i, :len(l)] = torch.tensor(l, dtype=torch.int32)
+        n_child = torch.tensor([len(l) for l in alt_links], dtype=torch.int32)
+        root = torch.tensor(list(root_links), dtype=torch.int32)
+        hit = (root.to(device), child.to(device), n_child.to(device), max_child)
+        _links_cache[key] = hit
+    return hit
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+class _DiscLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input_scores, alt_scores, txt_in, txt_alt, alt_alt, depth_mask, root, child, n_child, max_child, n_update):
+        C.require_cuda(input_scores, alt_scores, txt_in, txt_alt, alt_alt, depth_mask)
+        B, S = input_scores.shape
+        _, N, K = alt_scores.shape
+        sh = C.DiscLossShape(B, S, N, K, min(int(n_update), N), root.numel(), max_child)
+        args = [_f32c(t) for t in (input_scores, alt_scores, depth_mask, txt_in, txt_alt, alt_alt)]
+        out = torch.empty(5, dtype=torch.float32, device=input_scores.device)
+        C.check(C.lib().bg_disc_loss_fwd(ctypes.byref(sh), *[C.ptr(t) for t in args], C.ptr(root), C.ptr(child), C.ptr(n_child),
+                                         C.ptr(out), C.stream_ptr()), "bg_disc_loss_fwd")
+        ctx.save_for_backward(*args, root, child, n_child)
+        ctx.sh = sh
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        *args, root, child, n_child = ctx.saved_tensors
+        sh = ctx.sh
+        # out = [input, alt, vh_in, vh_alt, vh] with vh = (vh_in + vh_alt) / 2: fold the parts' gradients into vh's
+        g = torch.stack((g_out[0], g_out[1], g_out[4])).contiguous().float()
+        d = [torch.empty_like(args[i]) for i in (0, 1, 3, 4, 5)]
+        C.check(C.lib().bg_disc_loss_bwd(ctypes.byref(sh), *[C.ptr(t) for t in args], C.ptr(root), C.ptr(child), C.ptr(n_child),
+                                         C.ptr(g), *[C.ptr(t) for t in d], C.stream_ptr()), "bg_disc_loss_bwd")
+        d_in, d_alt, d_txt_in, d_txt_alt, d_alt_alt = d
+        return d_in, d_alt, d_txt_in, d_txt_alt, d_alt_alt, None, None, None, None, None, None
+
+
+def disc_losses(input_scores, alt_scores, txt_in, txt_alt, alt_alt, depth_mask, root_links, alt_links, n_update):
+    """Fused DiscriminatorLoss.py:4-74.  input_scores (B,S); alt_scores (B,N,K); txt_in/txt_alt (B,S); alt_alt (N,B,K);
+    depth_mask (N,K).  -> fp32 [inputLoss, alterationLoss, ValueHead-InputLoss, ValueHead-AltLoss, ValueHeadLoss]
+    (differentiate through elements 0, 1 and 4; 2 and 3 are reported parts of 4)."""
+    root, child, n_child, max_child = link_tables(root_links, alt_links, input_scores.device)
+    out = _DiscLosses.apply(input_scores, alt_scores, txt_in, txt_alt, alt_alt, depth_mask, root, child, n_child, max_child, n_update)
+    return out
+
+
+class _RlLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask, wA, wB, wC, ignore_in, ignore_alt,
+                probs_input):
+        C.require_cuda(label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask)
+        B, S = input_scores.shape
+        _, N, K = alt_scores.shape
+        sh = C.RlLossShape(B, S, N, K, float(wA), float(wB), float(wC), int(ignore_in), int(ignore_alt),
+                           int(depth_mask is not None), int(probs_input))
+        args = [_f32c(t) for t in (input_scores, alt_scores, in_head, alt_head, label_lp, alt_lp)]
+        mask = _f32c(depth_mask) if depth_mask is not None else None
+        out = torch.empty(2, dtype=torch.float32, device=input_scores.device)
+        C.check(C.lib().bg_rl_loss_fwd(ctypes.byref(sh), *[C.ptr(t) for t in args], C.ptr(mask), C.ptr(out), C.stream_ptr()),
+                "bg_rl_loss_fwd")
+        ctx.save_for_backward(*args, *([mask] if mask is not None else []))
+        ctx.sh = sh
+        ctx.shapes = (label_lp.shape, alt_lp.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved = ctx.saved_tensors
+        args, mask = list(saved[:6]), (saved[6] if len(saved) > 6 else None)
+        d_label, d_alt = torch.empty_like(args[4]), torch.empty_like(args[5])
+        g = g_out.contiguous().float()
+        C.check(C.lib().bg_rl_loss_bwd(ctypes.byref(ctx.sh), *[C.ptr(t) for t in args], C.ptr(mask), C.ptr(g), C.ptr(d_label),
+                                       C.ptr(d_alt), C.stream_ptr()), "bg_rl_loss_bwd")
+        return (d_label.view(ctx.shapes[0]), d_alt.view(ctx.shapes[1])) + (None,) * 11
+
+
+def rl_losses(label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask, wA=1.0, wB=1.0, wC=1.0,
+              ignore_input=True, ignore_alt=True, probs_input=False):
+    """Fused AdvantageCalculations.py:5-46 + ReinforceLoss.py:21-52 + GeneratorLosses.py:96-121.
+    label_lp (B,S-1), alt_lp (B,N,K): log-probs (or probs with probs_input=True) of the true / sampled tokens; the
+    discriminator tensors carry no gradient.  -> fp32 [loss-RL-input, loss-RL-alterations]."""
+    return _RlLosses.apply(label_lp, alt_lp, input_scores.detach(), alt_scores.detach(), in_head.detach(), alt_head.detach(),
+                           depth_mask, wA, wB, wC, ignore_input, ignore_alt, probs_input)

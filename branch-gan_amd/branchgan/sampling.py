@@ -122,6 +122,8 @@ class MaskedProbs:
 
     def materialize(self):
         p, ids = self.probs, self.input_ids
+        if hasattr(p, "materialize"):
+            p = p.materialize()
         if self.block:
             head = torch.scatter(p[:, :-1], dim=-1, index=ids[:, 1:].unsqueeze(-1), value=0)
             return torch.cat((head, p[:, -1:]), dim=1) if self.include_final else head

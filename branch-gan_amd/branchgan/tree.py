@@ -1,0 +1,311 @@
+"""Prediction tree and the generator / discriminator tree forwards — host side.
+
+Mirrors BranchPredictions/MultiStepPrediction.py (reference): PredictionTreeNode, multiStepGenForward,
+multiStepDiscForward, clearTree, getSubNodeListTreeStructure, getRandomNodesFromRule keep their names, arguments and the
+node fields callers read.  What changed underneath (all exactness-preserving):
+  * no mask tensors: a node's mask is the descriptor (ctx_len = sparseIndex + 1, its ancestor path);
+  * no KV concatenation: ancestors' (k, v) are passed to the attention kernel as slots;
+  * nothing over the vocabulary is materialised: ids come from bg_topn_select on the logits of the K branch rows only
+    (quirk 4), label / sampled-token log-probs from bg_softmax_stats (one read of the logits, own backward);
+  * the discriminator scores EVERY branch node in ONE forward (multiStepDiscForward walks node by node in the
+    reference, :357-362): query (node, k) sees text[0..s_k], its ancestors' column k and itself.
+"""
+import torch
+
+from . import ops
+from . import sampling as SamplingStrategies
+from .models import BranchPast, DiscriminatorOutput
+from .sampling import SamplingTechniques
+
+_NOISE_TECHNIQUES = (SamplingTechniques.SAMPLE_NO_REPLACEMENT, SamplingTechniques.EPSILON_SAMPLE_NO_REPLACEMENT,
+                     SamplingTechniques.INVERSE_TOP_K_SAMPLE_NO_REPLACEMENT, SamplingTechniques.TOP_P_SAMPLE_NO_REPLACEMENT)
+
+
+class PredictionTreeNode:
+    """MultiStepPrediction.py:6-200.  `past` = per layer (k, v) of THIS node's tokens; `logProbs` is new (log of `probs`)."""
+
+    def __init__(self, ids, parent=None, depth=0, beam=0, probs=None, isRandom=False, sparseIndex=None, rootSeqSize=None,
+                 discPreds=None, valueHeadData=None, logProbs=None):
+        self.isRandom, self.parent, self.children = isRandom, parent, []
+        self.depth, self.probs, self.logProbs, self.beam, self.ids = depth, probs, logProbs, beam, ids
+        self.numPredictionIDs = ids.shape[1]
+        self.sparseIndex = sparseIndex
+        self.rootSeqSize = ids.shape[1] if depth == 0 else rootSeqSize
+        self.valueHeadData, self.discPreds = valueHeadData, discPreds
+        self.attMask = None
+        self.past = None
+
+    def addGeneratorPredictionToNode(self, ids, past, attMask, probs, isRandomSamples=None, logProbs=None):
+        self.past, self.attMask = past, attMask
+        isRandomSamples = [False] * ids.shape[1] if isRandomSamples is None else isRandomSamples
+        for i in range(ids.shape[1]):
+            beam = i if self.parent is None else self.beam
+            self.children.append(PredictionTreeNode(ids[:, i], self, self.depth + 1, beam, probs[:, :, i], isRandomSamples[i],
+                                                    sparseIndex=self.sparseIndex, rootSeqSize=self.rootSeqSize,
+                                                    logProbs=None if logProbs is None else logProbs[:, :, i]))
+
+    def addDiscPredictionToNode(self, discPreds, past, attMask, valueHeadData=None):
+        self.past, self.attMask, self.discPreds, self.valueHeadData = past, attMask, discPreds, valueHeadData
+
+    def getPaddedPosIDs(self, padValue=9999):
+        if self.depth == 0 or self.ids.shape[1] == self.rootSeqSize:
+            return self.sparseIndex + self.depth
+        pad = torch.ones(self.rootSeqSize - self.ids.shape[1], device=self.sparseIndex.device) * padValue
+        return torch.cat((self.sparseIndex + self.depth, pad), dim=0)
+
+    def getPaddedAlterationProbs(self, padValue=0.00001):
+        if self.depth == 0 or self.ids.shape[1] == self.rootSeqSize:
+            return self.probs
+        pad = torch.zeros((self.probs.shape[0], self.rootSeqSize - self.probs.shape[1]), device=self.probs.device) + padValue
+        return torch.cat((self.probs, pad), dim=1)
+
+    def getLeaves(self, includeRandomNodes=True):
+        if not self.children:
+            return self
+        out = []
+        for c in self.children:
+            if includeRandomNodes or not c.isRandom:
+                r = c.getLeaves(includeRandomNodes)
+                out.extend(r if isinstance(r, list) else [r])
+        return out
+
+    def getSubNodes(self):
+        out = []
+        for n in self.children:
+            out.append(n)
+            out.extend(n.getSubNodes())
+        return out
+
+    def ancestors(self):
+        """Branch ancestors in depth order (root excluded)."""
+        chain, n = [], self.parent
+        while n is not None and n.depth > 0:
+            chain.append(n)
+            n = n.parent
+        return chain[::-1]
+
+    def root(self):
+        n = self
+        while n.parent is not None:
+            n = n.parent
+        return n
+
+    def getAttentionMask(self, batchSize, device):
+        """The reference's bool mask (:92-127), built arithmetically on demand (debug / compat only)."""
+        if self.depth == 0:
+            return None
+        S, K = self.rootSeqSize, self.numPredictionIDs
+        sp = self.sparseIndex.to(device)
+        ctx = torch.arange(1, K + 1, device=device) if S == K else sp + 1
+        text = torch.arange(S, device=device).unsqueeze(0) < ctx.unsqueeze(1)
+        anc = torch.eye(K, dtype=torch.bool, device=device).repeat(1, self.depth - 1)
+        m = torch.cat((text, anc, torch.ones(K, 1, dtype=torch.bool, device=device)), dim=1)
+        return m[None, None].expand(batchSize, 1, K, -1)
+
+    def getFullPast(self):
+        """Reference form (:140-152): per layer (k, v) concatenated root-first.  The engine never calls this."""
+        if self.depth == 0:
+            return None
+        chain = [self.root()] + self.ancestors()
+        L = len(chain[0].past)
+        return [(torch.cat([c.past[l][0] for c in chain], dim=-2), torch.cat([c.past[l][1] for c in chain], dim=-2)) for l in range(L)]
+
+    def branchPast(self, ctx_len):
+        """Engine form of (getFullPast, getAttentionMask): text KV, ancestor slots, descriptor."""
+        root, anc = self.root(), self.ancestors()
+        L = len(root.past)
+        return BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[a.past[l] for a in anc] for l in range(L)],
+                          ctx_len=ctx_len, paths=[list(range(len(anc) + 1))], n_query_nodes=1)
+
+    def producePredictionStep(self, device):
+        """(:154-166) ids, int32 position ids, past, mask — in the engine form (BranchPast carries past AND mask)."""
+        B = self.ids.shape[0]
+        if self.depth == 0:
+            pos = torch.arange(self.ids.shape[-1], dtype=torch.int32, device=device)
+            return self.ids.to(device), pos.unsqueeze(0).expand(B, -1), None, None
+        pos = (self.sparseIndex.to(device) + self.depth).to(torch.int32).unsqueeze(0).expand(B, -1)
+        return self.ids.to(device), pos, self.branchPast(ctx_len_of(self.sparseIndex, device)), None
+
+    def clearNode(self, clearAll=False, clearAttMask=False, clearSparseIndex=False):
+        if clearAll:
+            self.ids = None
+            self.discPreds = self.valueHeadData = self.probs = self.logProbs = None
+        if clearAttMask or clearAll:
+            self.attMask = None
+        self.past = None
+        if clearSparseIndex:
+            self.sparseIndex = None
+
+    def calculateNumNodes(self):
+        return 1 + sum(n.calculateNumNodes() for n in self.children)
+
+
+def ctx_len_of(sparseIndex, device):
+    return (sparseIndex.to(device) + 1).to(torch.int32).contiguous()
+
+
+def clearTree(root, clearAll=False, clearAttMask=False, clearSparseIndex=False):
+    for n in root.children:
+        clearTree(n, clearAll, clearAttMask, clearSparseIndex)
+    root.clearNode(clearAll, clearAttMask, clearSparseIndex)
+
+
+def getSubNodeListTreeStructure(root, subNodes):
+    for i, n in enumerate(subNodes):
+        n.listIndex = i
+    alterationLinks = [[c.listIndex for c in n.children] for n in subNodes]
+    rootLinks = [n.listIndex for n in root.children if getattr(n, 'listIndex', None) is not None]
+    return rootLinks, alterationLinks
+
+
+def getRandomNodesFromRule(strat, params, numAlterations):
+    if strat.name not in SamplingStrategies.RANDOM_TECHNIQUES:
+        return None
+    if strat == SamplingTechniques.RANDOM:
+        return [True] * numAlterations
+    return [False] * (numAlterations - params['numRandomSamples']) + [True] * params['numRandomSamples']
+
+
+def _sample_rows(logits2d, row_map, labels, numSamples, strat, params, B, T_out, noise_fn):
+    """ids (B, n, T_out) for the selected rows of a (rows, V) logits tensor.  TOP_K works on the logits directly
+    (softmax is monotone); the noise-consuming techniques need the reference's probs bits, so the probs of those few
+    rows are formed (B*K rows, not B*S) and go through the probs entry points."""
+    V = logits2d.shape[-1]
+    blocked = labels.reshape(-1, 1) if labels is not None else None
+    if strat == SamplingTechniques.TOP_K:
+        ids = ops.topn_select(logits2d, numSamples, blocked=blocked, blocked_value=float("-inf"), row_map=row_map)
+        return ids.view(B, T_out, numSamples).permute(0, 2, 1)
+    rows = logits2d if row_map is None else logits2d[row_map]
+    probs = torch.softmax(rows.float(), dim=-1).view(B, T_out, V)
+    noise = None
+    if strat in _NOISE_TECHNIQUES:
+        noise = noise_fn((B, T_out, V), probs.device) if noise_fn is not None else None
+    # express "block label of row t" through a synthetic inputIDs whose entry t+1 is that label
+    if labels is not None:
+        lab = labels.view(B, T_out)
+        fake_ids = torch.cat((torch.zeros(B, 1, dtype=lab.dtype, device=lab.device), lab), dim=1)      # (B, T_out+1)
+        probs_ext = torch.cat((probs, probs[:, -1:]), dim=1)                                             # dummy last row
+        alt, _ = SamplingStrategies.sampleFromGeneratorDistribution(probs_ext.detach(), numSamples, fake_ids, strat,
+                                                                    blockSamplingOfLabels=True, includeFinalTimeStep=False,
+                                                                    noise=noise, **_clean(params))
+    else:
+        fake_ids = torch.zeros(B, T_out, dtype=torch.int64, device=probs.device)
+        alt, _ = SamplingStrategies.sampleFromGeneratorDistribution(probs.detach(), numSamples, fake_ids, strat,
+                                                                    blockSamplingOfLabels=False, includeFinalTimeStep=True,
+                                                                    noise=noise, **_clean(params))
+    return alt[:, :, 1:]
+
+
+def _clean(params):
+    return {k: v for k, v in params.items() if k not in ('includeFinalTimeStep', 'blockSamplingOfLabels', 'dropoutRate')}
+
+
+def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=True, clearFullTree=False, verbose=False,
+                        sparseIndex=None, noise_fn=None):
+    """MultiStepPrediction.py:243-332.  Returns (root, firstPrediction, firstProbs (lazy), maskedProbs (lazy));
+    additionally root.labelLogProbs (B, S-1) = log prob of every true next token (for MLE and REINFORCE)."""
+    inputIDs = inputIDs.to(device)
+    B, S = inputIDs.shape
+    firstRule = sampleRules[0]
+    firstOutput = generator.forward({'input_ids': inputIDs, 'use_cache': True, 'returnLmLogits': True,
+                                     'dropoutRate': firstRule.samplingParams.get('dropoutRate', None)})
+    logits = firstOutput.prediction.logits
+    V = logits.shape[-1]
+    firstRule.samplingParams['includeFinalTimeStep'] = True
+    if sparseIndex is None:
+        sparseIndex = torch.arange(S, device=device)
+    sparseIndex = sparseIndex.to(device).long()
+    K = sparseIndex.numel()
+    ctx_len = ctx_len_of(sparseIndex, device)
+    noise_fn = noise_fn or SamplingStrategies.getRand
+
+    # rows to sample: (b, s_k); the label of row s is inputIDs[s + 1] (none for the last position)   [quirks 4, 5]
+    logits2d = logits.reshape(B * S, V)
+    row_map = (torch.arange(B, device=device).unsqueeze(1) * S + sparseIndex.unsqueeze(0)).reshape(-1)
+    nxt = torch.cat((inputIDs[:, 1:], torch.full((B, 1), -1, dtype=inputIDs.dtype, device=device)), dim=1)
+    labels_k = nxt[:, sparseIndex]
+    n0 = firstRule.numAlterations
+    sparseAltIDs = _sample_rows(logits2d.detach(), row_map, labels_k, n0, firstRule.samplingStrategy, firstRule.samplingParams,
+                                B, K, noise_fn)                                          # (B, n0, K)
+
+    # one pass over the logits: lse, log p(label) for every row, log p(sampled ids) on the branch rows   [quirk 6]
+    gather = torch.full((B, S, 1 + n0), -1, dtype=torch.int64, device=device)
+    gather[:, :, 0] = nxt
+    gather[:, sparseIndex, 1:] = sparseAltIDs.permute(0, 2, 1)
+    _, logp = ops.softmax_stats(logits, gather)
+    labelLogProbs = logp[:, :-1, 0]                                                      # (B, S-1)
+    altLogProbs = logp[:, sparseIndex, 1:]                                               # (B, K, n0)
+    inputProbs = torch.cat((torch.zeros(B, 1, device=device), labelLogProbs.exp()), dim=-1)
+
+    root = PredictionTreeNode(inputIDs, sparseIndex=sparseIndex, probs=inputProbs)
+    root.labelLogProbs = labelLogProbs
+    randomNodeInfo = getRandomNodesFromRule(firstRule.samplingStrategy, firstRule.samplingParams, n0)
+    root.addGeneratorPredictionToNode(sparseAltIDs, firstOutput.prediction.past_key_values, None, altLogProbs.exp(),
+                                      isRandomSamples=randomNodeInfo, logProbs=altLogProbs)
+
+    for rule in sampleRules[1:]:
+        for node in root.getLeaves(rule.continueFromRandom):
+            predIDs, positionalIDs, past, _ = node.producePredictionStep(device)
+            output = generator.forward({'input_ids': predIDs, 'position_ids': positionalIDs, 'textualPast': past,
+                                        'returnLmLogits': True, 'use_cache': True,
+                                        'dropoutRate': rule.samplingParams.get('dropoutRate', None)})
+            if node.beam == 0 and rule.firstBeamSamplingStrategy is not None:
+                strat, params = rule.firstBeamSamplingStrategy, rule.firstBeamSamplingParams
+                numAlterations = rule.numAlterations + params['numRandomSamples']
+            else:
+                strat, params, numAlterations = rule.samplingStrategy, rule.samplingParams, rule.numAlterations
+            params['includeFinalTimeStep'] = True
+            params['blockSamplingOfLabels'] = False
+            step_logits = output.prediction.logits                                        # (B, K, V)
+            altIDs = _sample_rows(step_logits.detach().reshape(B * K, V), None, None, numAlterations, strat, params, B, K, noise_fn)
+            _, lp = ops.softmax_stats(step_logits, altIDs.permute(0, 2, 1).contiguous())  # (B, K, n)
+            node.addGeneratorPredictionToNode(altIDs, output.prediction.past_key_values, None, lp.exp(),
+                                              getRandomNodesFromRule(strat, params, numAlterations), logProbs=lp)
+    if clearTreePast or clearFullTree:
+        clearTree(root, clearFullTree)
+    return root, firstOutput.prediction, firstOutput.classProbs, \
+        SamplingStrategies.MaskedProbs(firstOutput.classProbs, inputIDs, True, True)
+
+
+def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePast=True, clearFullTree=False,
+                         dualValueHeads=False):
+    """MultiStepPrediction.py:335-366, as TWO forwards: the root pass and one pass over every branch node."""
+    root = predictionTreeRoot
+    nodes = root.getSubNodes()
+    ids = root.ids.detach().to(device)
+    B, S = ids.shape
+
+    def finish(node, pred, sl=None):
+        trans = pred.transformerPred
+        if dualValueHeads:
+            _, inV, altV = discriminator.forward({'pred': trans}, doDiscForward=False, doFinalizeSinglePrediction=True)
+        return (inV, altV) if dualValueHeads else (None, None)
+
+    out = discriminator.forward({'input_ids': ids, 'use_cache': True, 'output_hidden_states': False},
+                                doDiscForward=False, doTransformerPassWithPrediction=True)
+    inV, altV = finish(root, out)
+    root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction), out.transformerPred.past_key_values, None,
+                                 {'InputValue': inV, 'AlterationsValue': altV} if dualValueHeads else None)
+    if nodes:
+        sparseIndex = root.sparseIndex.to(device)
+        K, N = sparseIndex.numel(), len(nodes)
+        index = {id(n): i for i, n in enumerate(nodes)}
+        paths = [[index[id(a)] for a in n.ancestors()] + [i] for i, n in enumerate(nodes)]
+        all_ids = torch.stack([n.ids.detach() for n in nodes], dim=1).reshape(B, N * K).to(device)
+        depths = torch.tensor([n.depth for n in nodes], device=device)
+        pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
+        L = len(root.past)
+        past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
+                          ctx_len=ctx_len_of(sparseIndex, device), paths=paths, n_query_nodes=N)
+        out = discriminator.forward({'input_ids': all_ids, 'position_ids': pos, 'textualPast': past, 'use_cache': True},
+                                    doDiscForward=False, doTransformerPassWithPrediction=True)
+        inV, altV = finish(None, out)
+        pred = out.prediction.view(B, N, K)
+        kv = out.transformerPred.past_key_values
+        for i, n in enumerate(nodes):
+            vh = {'InputValue': inV.view(B, N, K, 1)[:, i], 'AlterationsValue': altV.view(B, N, K, 1)[:, i]} if dualValueHeads else None
+            node_kv = [(k.unflatten(2, (N, K))[:, :, i], v.unflatten(2, (N, K))[:, :, i]) for k, v in kv]
+            n.addDiscPredictionToNode(DiscriminatorOutput(pred[:, i]), node_kv, None, vh)
+    if clearTreePast or clearFullTree:
+        clearTree(root, clearFullTree, clearAttMask=True, clearSparseIndex=True)
+    return root

@@ -191,6 +191,7 @@ typedef struct {
   float wA, wB, wC;
   int ignore_input, ignore_alt;   /* IncorrectValueHeadsPolicy.IGNORE_SAMPLE for input / alterations */
   int use_depth_mask;             /* 0: reference's depthMask=None branch (mean over [:, :, :-1]) */
+  int probs_input;                /* 0: label_logp / alt_logp hold log-probs;  1: they hold probabilities */
 } bg_rl_loss_shape;
 int bg_rl_loss_fwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
                    const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,

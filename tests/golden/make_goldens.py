@@ -319,8 +319,8 @@ def dump_tree(root, prefix, out):
 def g3_g5(family, tag, rules_spec, seed, sparse, B=2, S=12):
     out = {}
     torch.manual_seed(seed)
-    cfg_g = tiny_cfg(family)
-    cfg_d = tiny_cfg(family, hidden=16, heads=2)
+    cfg_g = tiny_cfg(family, hidden=64, heads=2)      # head dim 32: the smallest the HIP attention kernels take
+    cfg_d = tiny_cfg(family, hidden=32, heads=1)
     setup = GanSetup.GannSetup(cfg_g, cfg_d)
     # post_init() leaves heads at N(0, .02): scale up a little so scores are not all ~0.5
     with torch.no_grad():

@@ -31,7 +31,7 @@ def load_case(g, family, requires_grad=False):
     if requires_grad:
         sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
     cfg_g = M.config_from_state_dict(sd, "generator.generator.", family, n_head=2)
-    cfg_d = M.config_from_state_dict(sd, "discriminator.nonResidualModel.", family, n_head=2)
+    cfg_d = M.config_from_state_dict(sd, "discriminator.nonResidualModel.", family, n_head=1)
     rules = [(int(a), int(t), {}) for a, t in g["rules"].tolist()]
     return sd, cfg_g, cfg_d, rules, torch.from_numpy(g["inputIDs"]), torch.from_numpy(g["sparseIndex"])
 
