@@ -12,6 +12,31 @@ from . import _capi as C
 
 _ws_cache = {}
 
+# Optional per-kernel timing with HIP events on the launch stream (bench.py turns it on): name -> [(start, end), ...]
+TIMING = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            TIMING.setdefault(self.name, []).append((self.start, end))
+
+
+def timing_summary():
+    """name -> (launches, mean ms) from the recorded events (synchronises)."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in (TIMING or {}).items()}
+
 
 def _workspace(nbytes, device):
     """Grow-only per-device scratch for kernels that need one (top-n partials)."""
@@ -57,10 +82,11 @@ def topn_select(scores, n, noise=None, blocked=None, blocked_value=0.0, row_map=
     lib = C.lib()
     ws_bytes = lib.bg_topn_workspace_bytes(rows, V, n)
     ws = _workspace(ws_bytes, scores.device)
-    C.check(lib.bg_topn_select(C.ptr(scores), C.dtype_code(scores), rows, V, scores.stride(0), C.ptr(row_map),
-                               C.ptr(noise), noise.stride(0) if noise is not None else 0,
-                               C.ptr(blocked), nb, float(blocked_value), n, C.ptr(ids), C.ptr(keys),
-                               C.ptr(ws), ws.numel() if ws is not None else 0, C.stream_ptr()), "bg_topn_select")
+    with _timed("topn_select"):
+        C.check(lib.bg_topn_select(C.ptr(scores), C.dtype_code(scores), rows, V, scores.stride(0), C.ptr(row_map),
+                                   C.ptr(noise), noise.stride(0) if noise is not None else 0,
+                                   C.ptr(blocked), nb, float(blocked_value), n, C.ptr(ids), C.ptr(keys),
+                                   C.ptr(ws), ws.numel() if ws is not None else 0, C.stream_ptr()), "bg_topn_select")
     return (ids, keys) if return_keys else ids
 
 
@@ -99,8 +125,9 @@ class _SoftmaxStats(torch.autograd.Function):
         n_ids = ids2.shape[1]
         lse = torch.empty(rows, dtype=torch.float32, device=x.device)
         logp = torch.empty((rows, n_ids), dtype=torch.float32, device=x.device)
-        C.check(C.lib().bg_softmax_stats_fwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids,
-                                             C.ptr(lse), C.ptr(logp), C.stream_ptr()), "bg_softmax_stats_fwd")
+        with _timed(f"softmax_stats_fwd[{rows}]"):
+            C.check(C.lib().bg_softmax_stats_fwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids,
+                                                 C.ptr(lse), C.ptr(logp), C.stream_ptr()), "bg_softmax_stats_fwd")
         ctx.save_for_backward(x, ids2, lse)
         ctx.in_shape = logits.shape
         ctx.mark_non_differentiable(ids)
@@ -114,8 +141,9 @@ class _SoftmaxStats(torch.autograd.Function):
         g_lse = g_lse.reshape(rows).contiguous().float() if g_lse is not None else None
         g_logp = g_logp.reshape(rows, n_ids).contiguous().float() if g_logp is not None else None
         dx = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
-        C.check(C.lib().bg_softmax_stats_bwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids, C.ptr(lse),
-                                             C.ptr(g_lse), C.ptr(g_logp), C.ptr(dx), C.stream_ptr()), "bg_softmax_stats_bwd")
+        with _timed(f"softmax_stats_bwd[{rows}]"):
+            C.check(C.lib().bg_softmax_stats_bwd(C.ptr(x), C.dtype_code(x), rows, V, x.stride(0), C.ptr(ids2), n_ids, C.ptr(lse),
+                                                 C.ptr(g_lse), C.ptr(g_logp), C.ptr(dx), C.stream_ptr()), "bg_softmax_stats_bwd")
         return dx.view(ctx.in_shape), None
 
 
@@ -190,9 +218,10 @@ class _BranchAttention(torch.autograd.Function):
         out = torch.empty((B, H, NQ, K, Dh), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=q.device)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
-        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
-                                           _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
-                                           C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        with _timed("branch_attn_fwd"):
+            C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
+                                               _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
+                                               C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
         ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots_k, *slots_v)
         ctx.meta = (max_path, scale, len(slots_k))
         ctx.mark_non_differentiable(lse)
@@ -212,11 +241,12 @@ class _BranchAttention(torch.autograd.Function):
         dvs = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in slots_k]
         delta = torch.empty_like(lse)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
-        C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
-                                           _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
-                                           C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text),
-                                           _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
-                "bg_branch_attn_bwd")
+        with _timed("branch_attn_bwd"):
+            C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
+                                               _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
+                                               C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text),
+                                               _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
+                    "bg_branch_attn_bwd")
         return (dq, dk_text, dv_text, None, None, None, None, None, None, *dks, *dvs)
 
 

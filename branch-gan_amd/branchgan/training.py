@@ -1,0 +1,163 @@
+"""Batch-sharded data-parallel training step — host side.
+
+Mirrors Training/SpawnedExperiment.py:47-82,165-191 (one process per GPU, per-rank batch split, rank-0-only logging),
+Training/Optimizers.py:50-92 (OptimizerWrapper.performUpdateStep) and the step body of Training/TrainingLoop.py:129-158.
+
+MI355X design: the reference wraps G and D in DDP (find_unused_parameters=True) and all-reduces on EVERY micro-step and every
+DDP.forward (one per tree node).  Here each model owns one flat fp32 gradient arena that its parameters' .grad tensors are
+views of; after the backward of an optimizer step the arena is all-reduced in a few large RCCL buckets (xGMI links are
+point-to-point: fewer, larger collectives) on a side stream, overlapping the generator's reduction with the discriminator's
+backward.  Parameters that never receive a gradient (generator valueHead, discriminator LM head) are left out of the arena.
+Mathematically identical to the reference's averaging (sum / world).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def worker_batch_size(batchSize, worldSize, rank):
+    """SpawnedExperiment.py:63-68: floor(B / W), the remainder spread over the first ranks."""
+    return batchSize // worldSize + (1 if rank < batchSize % worldSize else 0)
+
+
+def init_data_parallel(backend=None):
+    """Reads the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one process per GPU.
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "12345")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradArena:
+    """Flat gradient storage of one model + bucketed all-reduce(sum)/world over the process group."""
+
+    def __init__(self, module, bucket_bytes=64 << 20, group=None):
+        self.module, self.bucket_bytes, self.group = module, bucket_bytes, group
+        self.arena = None
+        self.params = []
+        self.stream = None
+        self._work = []
+
+    def _build(self):
+        self.params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            view = self.arena[off:off + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+            off += p.numel()
+        if dev.type == "cuda":
+            self.stream = torch.cuda.Stream(device=dev)
+
+    def zero(self):
+        if self.arena is None:
+            for p in self.module.parameters():
+                p.grad = None
+        else:
+            self.arena.zero_()
+
+    def nbytes(self):
+        return 0 if self.arena is None else self.arena.numel() * 4
+
+    def reduce_async(self):
+        """Call after backward.  Launches the bucketed all-reduce; `wait()` before the optimizer step."""
+        if self.arena is None:
+            self._build()
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return
+        per = max(1, self.bucket_bytes // 4)
+        buckets = [self.arena[i:i + per] for i in range(0, self.arena.numel(), per)]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for b in buckets:
+                    b.div_(world)
+                    self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for b in buckets:
+                b.div_(world)
+                self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class OptimizerWrapper:
+    """Training/Optimizers.py:50-92.  backward every micro-step; optimizer step when stepCounter % gradAccum == 0 (so the
+    very first micro-step steps, quirk 11).  Under data parallelism the gradients are reduced once, right before that step."""
+
+    def __init__(self, model, optimizer, gradAccum=1, lossKey='loss', scheduler=None, arena=None):
+        self.model, self.optimizer, self.gradAccum, self.lossKey, self.scheduler = model, optimizer, gradAccum, lossKey, scheduler
+        self.arena = arena if arena is not None else GradArena(model)
+
+    def backward(self, losses, stepCounter):
+        losses[self.lossKey].backward()
+        if stepCounter % self.gradAccum == 0:
+            self.arena.reduce_async()
+            return True
+        return False
+
+    def finish(self, stepped):
+        if stepped:
+            self.arena.wait()
+            self.optimizer.step()
+            self.arena.zero()
+            if self.scheduler is not None:
+                self.scheduler.step()
+
+    def performUpdateStep(self, losses, stepCounter):
+        self.finish(self.backward(losses, stepCounter))
+
+
+def make_optimizer(params, name='adam', lr=1e-4, **kw):
+    """Optimizers.py:6-16 (NAME_TO_OPTIM)."""
+    table = {'adam': torch.optim.Adam, 'adagrad': torch.optim.Adagrad, 'sgd': torch.optim.SGD, 'rmsprop': torch.optim.RMSprop}
+    return table[name.lower()](params, lr=lr, **kw)
+
+
+def train_step(model, inputIDs, sampleConf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples=9999,
+               reinforcementLearningConfig=None, updateGen=True, updateDisc=True, **kwargs):
+    """The body of efficentTrainingLoop (TrainingLoop.py:141-152): one forward of the whole GAN step, generator backward,
+    discriminator backward, gradient reduction, both optimizer steps."""
+    discLosses, genLosses = model.trainForwardPassNoMetrics(inputIDs, sampleConf, numUpdateSamples, collectTreeDepthData=False,
+                                                            reinforcementLearningConfig=reinforcementLearningConfig, **kwargs)
+    g_step = generatorOptim.backward(genLosses, stepCounter) if updateGen else False        # G's all-reduce overlaps D's backward
+    d_step = discriminatorOptim.backward(discLosses, stepCounter) if updateDisc else False
+    generatorOptim.finish(g_step)
+    discriminatorOptim.finish(d_step)
+    return discLosses, genLosses
+
+
+def efficentTrainingLoop(model, trainDataset, numEpochs, generatorOptim, discriminatorOptim, trainingSamplingConf, numUpdateSamples,
+                         depthSchedule=None, reinforcementLearningConfig=None, log_every=0, rank=0, **kwargs):
+    """TrainingLoop.py:107-192 without evaluation / checkpointing (out of scope): epochs over an iterable of (B, S) id batches."""
+    stepCounter, history = 0, []
+    for epoch in range(int(numEpochs)):
+        for i, bIDs in enumerate(trainDataset):
+            conf = trainingSamplingConf.getNextSampleConf()
+            if depthSchedule is not None:
+                depthSchedule.updateSchedule(epoch, i, stepCounter)
+                conf = depthSchedule.setSampleConfDepth(conf)
+            d, g = train_step(model, bIDs, conf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples,
+                              reinforcementLearningConfig, **kwargs)
+            stepCounter += 1
+            if log_every and rank == 0 and stepCounter % log_every == 0:
+                history.append((stepCounter, float(d['loss']), float(g['loss'])))
+    return history

@@ -9,30 +9,9 @@
 // not below the threshold (≈ n·ln(V/n) times per wave); everything else costs one compare.  Items are
 // 64-bit composites (order-preserving key bits << 32 | ~index) so one integer compare gives the total
 // order "larger key first, NaN largest, equal keys by increasing index".  Waves merge through LDS by rank.
-#include "common.h"
+#include "topn_common.h"
 
 namespace bg {
-
-typedef unsigned long long u64;
-
-__device__ __forceinline__ uint32_t order_bits(float x) {
-  if (x != x) return 0xFFFFFFFFu;  // every NaN sorts first (torch: NaN is the largest)
-  x = x + 0.0f;                    // -0.0 -> +0.0 (they compare equal in torch.sort)
-  uint32_t u = __float_as_uint(x);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float order_bits_inv(uint32_t o) {
-  if (o == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
-  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
-}
-__device__ __forceinline__ u64 make_item(float key, uint32_t idx) {
-  return ((u64)order_bits(key) << 32) | (u64)(0xFFFFFFFFu - idx);
-}
-__device__ __forceinline__ u64 readlane64(u64 v, int l) {
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-  return ((u64)hi << 32) | lo;
-}
 
 struct TopnArgs {
   const void* scores;
@@ -50,24 +29,6 @@ struct TopnArgs {
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
-
-// Rank-merge `count` items held in LDS into the best n; each thread owns items t, t+blockDim, ...
-__device__ __forceinline__ void rank_merge_store(const u64* items, int count, int n, int64_t* out_ids, float* out_keys,
-                                                 u64* out_partial) {
-  for (int t = threadIdx.x; t < count; t += blockDim.x) {
-    u64 mine = items[t];
-    int rank = 0;
-    for (int j = 0; j < count; ++j) rank += (items[j] > mine) ? 1 : 0;
-    if (rank < n && mine != 0) {
-      if (out_partial) {
-        out_partial[rank] = mine;
-      } else {
-        out_ids[rank] = (int64_t)(0xFFFFFFFFu - (uint32_t)mine);
-        if (out_keys) out_keys[rank] = order_bits_inv((uint32_t)(mine >> 32));
-      }
-    }
-  }
-}
 
 template <typename T, bool HAS_NOISE>
 __global__ __launch_bounds__(256) void topn_partial_kernel(TopnArgs a) {

@@ -63,11 +63,13 @@ def sample_without_replacement(masked, n, noise, specified=False):
     return top_n(masked / noise, n, specified)
 
 
-def top_p_filter(probs, p):
+def top_p_filter(probs, p, specified=False):
     """SamplingStrategies.py:161-182.  Keeps sorted position i iff cumsum[i+1] <= p (the reference
     shifts its mask left by one, so the last token that fits is dropped); renormalises.  A row whose
-    top-1 mass exceeds p keeps nothing and becomes 0/0 = NaN."""
-    sorted_p, sorted_i = torch.sort(probs, dim=-1, descending=True)
+    top-1 mass exceeds p keeps nothing and becomes 0/0 = NaN.
+    specified=True sorts stably (equal probabilities in index order): which of several EQUAL probabilities
+    straddling the cut are kept is otherwise an artefact of ATen's unstable sort (see top_n)."""
+    sorted_p, sorted_i = torch.sort(probs, dim=-1, descending=True, stable=bool(specified))
     keep = torch.cumsum(sorted_p, dim=-1) <= p
     keep = torch.cat((keep[..., 1:], torch.zeros_like(keep[..., :1])), dim=-1)
     keep = torch.gather(keep, dim=-1, index=sorted_i.argsort())
