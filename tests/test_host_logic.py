@@ -1,0 +1,118 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels are launched)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as A
+from oracle import tree as OT
+
+
+def test_sampling_enum_and_rule_surface():
+    from branchgan import sampling as SS
+    assert [t.value for t in SS.SamplingTechniques] == list(range(10))
+    assert set(SS.RANDOM_TECHNIQUES) == {"RANDOM", "EPSILON_GREEDY", "EPSILON_SAMPLE", "EPSILON_SAMPLE_NO_REPLACEMENT"}
+    r = SS.SamplingRule(2, SS.SamplingTechniques.TOP_K, {"a": 1})
+    assert r.to_dict()["Strategy"] == "TOP_K" and r.firstBeamSamplingParams == {}
+    with pytest.raises(ValueError):
+        SS.apply_temperature(torch.ones(2, 3), 0)
+    with pytest.raises(ValueError):
+        SS.apply_noise(torch.ones(2, 3), 1.5)
+    p = torch.softmax(torch.randn(2, 3, 7), -1)
+    assert SS.apply_temperature(p, 1) is p
+
+
+def test_row_selection_matches_reference_blocking():
+    from branchgan import sampling as SS
+    ids = torch.arange(12).view(2, 6)
+    for block in (True, False):
+        for final in (True, False):
+            T_out, row_map, blocked = SS._row_selection(2, 6, 50, ids, block, final, "cpu")
+            assert T_out == (6 if final else 5)
+            assert (row_map is None) == final
+            if block:
+                want = ids[:, 1:6]
+                got = blocked.view(2, T_out)
+                assert torch.equal(got[:, :5], want)
+                if final:
+                    assert (got[:, 5] == -1).all()
+            else:
+                assert blocked is None
+
+
+def test_bool_mask_descriptor_roundtrip_and_rejection():
+    from branchgan.models import descriptor_from_bool_mask
+    sparse = torch.tensor([1, 4, 8])
+    m = OT.depth1_mask(2, sparse, 10)
+    for d in range(1, 4):
+        C = 10 + (d - 1) * 3
+        ctx, n_anc = descriptor_from_bool_mask(m, 3, C)
+        assert ctx.tolist() == [2, 5, 9] and n_anc == d - 1
+        m = OT.deeper_mask(m, 2, 3)
+    bad = OT.depth1_mask(2, sparse, 10).clone()
+    bad[0, 0, 1, 0] = False                         # hole in a text prefix
+    with pytest.raises(NotImplementedError):
+        descriptor_from_bool_mask(bad, 3, 10)
+    uneven = OT.depth1_mask(2, sparse, 10).clone()
+    uneven[1, 0, 0, 5] = True                       # differs across the batch
+    with pytest.raises(NotImplementedError):
+        descriptor_from_bool_mask(uneven, 3, 10)
+
+
+def test_tree_node_mask_and_structure_helpers():
+    from branchgan import tree
+    ids = torch.zeros(2, 10, dtype=torch.long)
+    sparse = torch.tensor([1, 4, 8])
+    root = tree.PredictionTreeNode(ids, sparseIndex=sparse, probs=torch.zeros(2, 10))
+    root.addGeneratorPredictionToNode(torch.zeros(2, 2, 3, dtype=torch.long), None, None, torch.zeros(2, 3, 2))
+    a, b = root.children
+    a.addGeneratorPredictionToNode(torch.zeros(2, 1, 3, dtype=torch.long), None, None, torch.zeros(2, 3, 1))
+    nodes = root.getSubNodes()
+    assert [n.depth for n in nodes] == [1, 2, 1] and [n.beam for n in nodes] == [0, 0, 1]
+    assert tree.getSubNodeListTreeStructure(root, nodes) == ([0, 2], [[1], [], []])
+    assert [n.depth for n in root.getLeaves()] == [2, 1]
+    # the arithmetic mask equals the reference's tensor mask
+    want = OT.deeper_mask(OT.depth1_mask(2, sparse, 10), 2, 3)
+    assert torch.equal(nodes[1].getAttentionMask(2, "cpu"), want)
+    assert nodes[1].getPaddedPosIDs().tolist() == [3, 6, 10] + [9999] * 7
+    assert tree.getRandomNodesFromRule(tree.SamplingTechniques.TOP_K, {}, 2) is None
+    assert tree.getRandomNodesFromRule(tree.SamplingTechniques.EPSILON_GREEDY, {"numRandomSamples": 1}, 3) == [False, False, True]
+
+
+def test_configs_and_schedules():
+    from branchgan import configs, sampling as SS
+    rules = [SS.SamplingRule(1, SS.SamplingTechniques.TOP_K, {}) for _ in range(16)]
+    conf = configs.SamplingConfig(rules, numSampleSequences=32, seed=7)
+    ids = torch.zeros(8, 128, dtype=torch.long)
+    sp = conf.getSparseIndex(ids, "cpu")
+    assert sp.numel() == 32 and bool((sp[1:] > sp[:-1]).all()) and int(sp.max()) <= 126
+    sched = configs.LinearUpdatesDepthSchedule(1, 1, 100, 8)
+    sched.updateSchedule(0, 0, 250)
+    assert sched.currentDepth == 3 and len(sched.setSampleConfDepth(conf).rules) == 3 and len(conf.rules) == 16
+    sched.updateSchedule(0, 0, 5000)
+    assert sched.currentDepth == 8
+    rr = configs.RoundRobinSamplingConfig([conf, "x"])
+    assert rr.getNextSampleConf() == "x" and rr.getNextSampleConf() is conf
+    c = configs.LMConfig.from_any("pythia-410m")
+    assert (c.head_dim, c.rotary_ndims, c.intermediate_size) == (64, 16, 4096)
+    assert configs.LMConfig.from_any("gpt2-small").vocab_size == 50257
+
+
+def test_state_dict_keys_match_reference(golden):
+    """Reference checkpoints load by key name: compare against the keys captured from the reference."""
+    from branchgan import configs, gan
+    for tag, family in (("neox_chain4", "gpt_neox"), ("gpt2_chain3", "gpt2")):
+        g = golden("g35_" + tag)
+        ref_keys = {k[4:] for k in g.files if k.startswith("sd::")}
+        mk = lambda hidden, heads: configs.LMConfig(family, 97, hidden, 2, heads, 64, intermediate_size=2 * hidden if family == "gpt_neox" else 0)
+        setup = gan.GannSetup(mk(64, 2), mk(32, 1), device="cpu")
+        mine = set(setup.state_dict().keys())
+        mask_buffers = {k for k in ref_keys if k.endswith((".bias", ".self_bias", ".masked_bias")) and (".attention." in k or ".attn." in k)
+                        and not k.endswith(("c_attn.bias", "c_proj.bias", "query_key_value.bias", "dense.bias"))}
+        assert mine == ref_keys - mask_buffers
+        setup.load_state_dict({k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd::")}, strict=True)
+
+
+def test_worker_batch_size_split():
+    from branchgan.training import worker_batch_size
+    assert [worker_batch_size(8, 3, r) for r in range(3)] == [3, 3, 2]
+    assert [worker_batch_size(64, 8, r) for r in range(8)] == [8] * 8
