@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     args = ap.parse_args()
 
     from branchgan import ops, training
@@ -113,9 +114,16 @@ def main():
     data = zipf_ids(n_batches * B, S, V, 1234 + rank).view(n_batches, B, S).to(device)
     use_amp = args.dtype == "bf16"
 
-    def step(i):
+    def eager_step(i):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
             return training.train_step(model, data[i % n_batches], conf, g_opt, d_opt, i, 9999, rl)
+
+    if args.eager:
+        step = eager_step
+    else:
+        from branchgan.graphs import GraphedTrainStep
+        graphed = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, torch.bfloat16 if use_amp else None)
+        step = lambda i: graphed.step(data[i % n_batches], i)
 
     def fence():
         torch.cuda.synchronize()
@@ -132,6 +140,10 @@ def main():
         d, g = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    if not args.eager:
+        graphed.check_nan()
+        for i in range(3):      # per-kernel HIP-event timing needs eager launches (events cannot sit inside a captured graph)
+            eager_step(args.warmup + args.steps + i)
     kernels = ops.timing_summary()
     ops.TIMING = None
     if world > 1:
@@ -157,7 +169,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if use_amp else "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "per_gpu_batch": B, "seq_len": S, "branch_points": wl["K"], "depth": wl["D"],
-                   "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}",
+                   "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay of fwd+bwd; all-reduce and Adam eager",
                    "precision": "bf16 autocast, fp32 master weights and accumulation" if use_amp else "fp32",
                    "weights": "random init", "final_losses": {"gen": float(g["loss"]), "disc": float(d["loss"])}},
         "roofline": {"bound": "hbm", "kernel": "softmax_stats_bwd_kernel (bg_softmax_stats_bwd, root pass)", "achieved": achieved,

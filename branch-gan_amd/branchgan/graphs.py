@@ -1,0 +1,85 @@
+"""HIP-graph capture of the launch-bound part of the train step.
+
+One Branch-GAN step is thousands of small launches (a GPT-2-small step at depth 4 issues ~5k kernels for ~50 ms of GPU work),
+so the host cannot keep the queue full.  The forward of the whole GAN step and both backward passes are captured ONCE into a
+hipGraph (torch.cuda.graph) and replayed per step; inputs (token ids, branch points) live in static device tensors that are
+overwritten before each replay, gradients accumulate into the static flat arenas of branchgan.training.GradArena.
+The gradient all-reduce (RCCL) and the optimizer steps stay outside the graph, so the data-parallel path is unchanged.
+The reference has no counterpart (it is eager PyTorch); results are identical to the eager step by construction.
+"""
+import copy
+
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, sampleConf, generatorOptim, discriminatorOptim, example_ids, numUpdateSamples=9999,
+                 reinforcementLearningConfig=None, amp_dtype=None, warmup=3):
+        self.model, self.g_opt, self.d_opt = model, generatorOptim, discriminatorOptim
+        self.rl, self.n_update, self.amp_dtype = reinforcementLearningConfig, numUpdateSamples, amp_dtype
+        self.src_conf = sampleConf
+        dev = example_ids.device
+        self.static_ids = example_ids.clone()
+        K = sampleConf.numSampleSequences or example_ids.shape[1]
+        self.static_sparse = torch.zeros(K, dtype=torch.long, device=dev)
+        self.conf = copy.copy(sampleConf)
+        self.conf.sparseIndex = self.static_sparse
+        self.graph = None
+        self.losses = None
+        self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
+        self._refresh_sparse(example_ids)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up: builds arenas, caches, workspaces
+            for i in range(warmup):
+                self._forward_backward()
+                self._finish(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._forward_backward()
+        ops.TIMING = timing
+        # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
+        self.g_opt.arena.zero()
+        self.d_opt.arena.zero()
+
+    def _refresh_sparse(self, ids):
+        src = self.src_conf
+        sp = src.sparseIndex if src.sparseIndex is not None else src.getSparseIndex(ids, ids.device)
+        if sp is None:
+            sp = torch.arange(ids.shape[1], device=ids.device)
+        self.static_sparse.copy_(sp.to(self.static_sparse.device), non_blocking=True)
+
+    def _forward_backward(self):
+        with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+            d, g = self.model.trainForwardPassNoMetrics(self.static_ids, self.conf, self.n_update, collectTreeDepthData=False,
+                                                        reinforcementLearningConfig=self.rl, checkNaN=False)
+        g[self.g_opt.lossKey].backward()
+        d[self.d_opt.lossKey].backward()
+        return d, g
+
+    def _finish(self, stepCounter):
+        for opt in (self.g_opt, self.d_opt):
+            if stepCounter % opt.gradAccum == 0:
+                opt.arena.reduce_async()
+        for opt in (self.g_opt, self.d_opt):
+            opt.finish(stepCounter % opt.gradAccum == 0)
+
+    def step(self, inputIDs, stepCounter):
+        """One train step: returns the (static) loss dicts; GanSetup.py:249-256's NaN guard is evaluated on the device and
+        raised by check_nan() (one host sync when the caller chooses, not one per loss key per step)."""
+        self.static_ids.copy_(inputIDs, non_blocking=True)
+        self._refresh_sparse(inputIDs)
+        self.graph.replay()
+        d, g = self.losses
+        self.nan_flag |= torch.isnan(g['loss'].detach())
+        self._finish(stepCounter)
+        return d, g
+
+    def check_nan(self):
+        if bool(self.nan_flag):
+            raise Exception("Generator loss loss is NaN")

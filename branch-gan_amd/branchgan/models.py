@@ -312,7 +312,8 @@ class GPTNeoXForCausalLM(_LMBase):
 # GPT-2 family
 # =================================================================================================
 def gelu_new(x):
-    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+    """GPT2MLP's `gelu_new` (tanh form), as ONE fused kernel each way instead of ~8 + ~20 elementwise launches."""
+    return F.gelu(x, approximate="tanh")
 
 
 class GPT2NonResidualAttention(nn.Module):

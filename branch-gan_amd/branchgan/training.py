@@ -129,6 +129,9 @@ class OptimizerWrapper:
 def make_optimizer(params, name='adam', lr=1e-4, **kw):
     """Optimizers.py:6-16 (NAME_TO_OPTIM)."""
     table = {'adam': torch.optim.Adam, 'adagrad': torch.optim.Adagrad, 'sgd': torch.optim.SGD, 'rmsprop': torch.optim.RMSprop}
+    params = list(params)
+    if name.lower() == 'adam' and 'fused' not in kw and params and params[0].is_cuda:
+        kw['fused'] = True        # one multi-tensor kernel per step instead of a chain of foreach launches
     return table[name.lower()](params, lr=lr, **kw)
 
 

@@ -140,6 +140,17 @@ class PredictionTreeNode:
         return 1 + sum(n.calculateNumNodes() for n in self.children)
 
 
+_depth_cache = {}
+
+
+def _depths_tensor(depths, device):
+    """Per-node depths on the device, cached per tree shape (no host-to-device copy inside a captured step)."""
+    key = (depths, str(device))
+    if key not in _depth_cache:
+        _depth_cache[key] = torch.tensor(depths, device=device)
+    return _depth_cache[key]
+
+
 def ctx_len_of(sparseIndex, device):
     return (sparseIndex.to(device) + 1).to(torch.int32).contiguous()
 
@@ -292,7 +303,7 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
         index = {id(n): i for i, n in enumerate(nodes)}
         paths = [[index[id(a)] for a in n.ancestors()] + [i] for i, n in enumerate(nodes)]
         all_ids = torch.stack([n.ids.detach() for n in nodes], dim=1).reshape(B, N * K).to(device)
-        depths = torch.tensor([n.depth for n in nodes], device=device)
+        depths = _depths_tensor(tuple(n.depth for n in nodes), device)
         pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
         L = len(root.past)
         past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
