@@ -9,6 +9,8 @@
 // not below the threshold (≈ n·ln(V/n) times per wave); everything else costs one compare.  Items are
 // 64-bit composites (order-preserving key bits << 32 | ~index) so one integer compare gives the total
 // order "larger key first, NaN largest, equal keys by increasing index".  Waves merge through LDS by rank.
+#include <type_traits>
+
 #include "topn_common.h"
 
 namespace bg {
@@ -26,13 +28,43 @@ struct TopnArgs {
   u64* partial;  // [rows][splits][n] when splits > 1
 };
 
-template <typename T> struct VecOf;
-template <> struct VecOf<float> { static constexpr int N = 4; };
-template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+template <typename T, bool HAS_NOISE> struct Tile;      // VEC elements per 16-byte load, U loads in flight per lane
+// PF: the next chunk's loads are issued before the current one is filtered (register double buffer)
+template <> struct Tile<float, false> { static constexpr int VEC = 4, U = 8; static constexpr bool PF = false; };
+template <> struct Tile<float, true> { static constexpr int VEC = 4, U = 4; static constexpr bool PF = false; };
+template <> struct Tile<bf16_t, false> { static constexpr int VEC = 8, U = 4; static constexpr bool PF = false; };
+template <> struct Tile<bf16_t, true> { static constexpr int VEC = 8, U = 2; static constexpr bool PF = false; };
+
+// The wave's running state: sorted list (lane i = i-th best), tau = its n-th item (0 while the list is not full) and
+// tau_key = the float key of tau (NaN while not full, so that "key < tau_key" is false for every key).
+struct WaveList {
+  u64 item, tau;
+  float tau_key;
+  int n, lane;
+  __device__ __forceinline__ void init(int n_, int lane_) { item = 0; tau = 0; tau_key = order_bits_inv(0); n = n_; lane = lane_; }
+  __device__ __forceinline__ void offer(u64 c) {     // wave-uniform c
+    if (c > tau) {
+      wave_insert(item, c, n, lane);
+      tau = readlane64(item, n - 1);
+      tau_key = tau == 0 ? order_bits_inv(0) : order_bits_inv((uint32_t)(tau >> 32));
+    }
+  }
+  // every lane may bring one item (0 = none); offered in lane order
+  __device__ __forceinline__ void offer_lanes(u64 mine) {
+    u64 bal = __ballot(mine != 0);
+    while (bal) {
+      const int L = __ffsll((unsigned long long)bal) - 1;
+      bal &= bal - 1;
+      offer(readlane64(mine, L));
+    }
+  }
+};
 
 template <typename T, bool HAS_NOISE>
 __global__ __launch_bounds__(256) void topn_partial_kernel(TopnArgs a) {
-  constexpr int VEC = VecOf<T>::N;
+  constexpr int VEC = Tile<T, HAS_NOISE>::VEC, U = Tile<T, HAS_NOISE>::U;
+  constexpr bool PF = Tile<T, HAS_NOISE>::PF;
+  constexpr int CH = 256 * VEC * U;     // elements per workgroup chunk; U*VEC <= 32 candidate bits per lane
   __shared__ u64 lds_items[4 * BG_MAX_TOPN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row = blockIdx.x;
@@ -40,7 +72,7 @@ __global__ __launch_bounds__(256) void topn_partial_kernel(TopnArgs a) {
   const int64_t in_row = a.row_map ? a.row_map[row] : row;
   const T* s = (const T*)a.scores + in_row * a.score_stride;
   const float* e = HAS_NOISE ? a.noise + row * a.noise_stride : nullptr;
-  const int64_t begin = (int64_t)split * a.seg_len;
+  const int64_t begin = min(a.V, (int64_t)split * a.seg_len);
   const int64_t end = min(a.V, begin + a.seg_len);
   const int n = a.n;
 
@@ -49,102 +81,164 @@ __global__ __launch_bounds__(256) void topn_partial_kernel(TopnArgs a) {
   for (int i = 0; i < BG_MAX_BLOCKED; ++i) {
     int64_t b = (i < a.n_blocked) ? a.blocked[row * a.n_blocked + i] : -1;
     blk[i] = (b >= 0 && b < a.V) ? (uint32_t)b : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < i; ++k)
+      if (blk[k] == blk[i]) blk[i] = 0xFFFFFFFFu;     // a repeated id counts once
+  }
+  auto is_blocked = [&](int64_t i) -> bool {
+    bool hit = false;
+#pragma unroll
+    for (int b = 0; b < BG_MAX_BLOCKED; ++b) hit |= (b < a.n_blocked) && (blk[b] == (uint32_t)i);
+    return hit;
+  };
+  // exact item of element i (the streaming loop below only filters; whatever passes is re-read here)
+  auto item_of = [&](int64_t i) -> u64 {
+    if (is_blocked(i)) return 0;                       // blocked elements enter once, in the prologue
+    float key = to_f32(s[i]);
+    if constexpr (HAS_NOISE) key = key / e[i];
+    return make_item(key, (uint32_t)i);
+  };
+
+  WaveList wl;
+  wl.init(n, lane);
+
+  // prologue: the blocked ids of this segment take their replacement score (wave 0 owns them)
+  if (wave == 0) {
+#pragma unroll
+    for (int b = 0; b < BG_MAX_BLOCKED; ++b) {
+      if (b >= a.n_blocked) break;
+      const int64_t i = blk[b];
+      if (blk[b] == 0xFFFFFFFFu || i < begin || i >= end) continue;    // wave-uniform
+      float key = a.blocked_value;
+      if constexpr (HAS_NOISE) key = key / e[i];
+      wl.offer(make_item(key, (uint32_t)i));
+    }
   }
 
-  u64 item = 0, tau = 0;        // 0 = empty (below every real item)
-  float tau_key = order_bits_inv(0);  // NaN: "key < tau_key" is false for every key => everything is a candidate
+  // per-element path for the unaligned head and the ragged tail
+  auto edge = [&](int64_t lo, int64_t hi) {
+    for (int64_t base = lo; base < hi; base += 256) {
+      const int64_t i = base + tid;
+      u64 mine = 0;
+      if (i < hi) {
+        float key = to_f32(s[i]);
+        if constexpr (HAS_NOISE) key = key / e[i];
+        if (!(key < wl.tau_key) && !is_blocked(i)) mine = make_item(key, (uint32_t)i);
+      }
+      wl.offer_lanes(mine);
+    }
+  };
 
-  // first 16-byte-aligned vector at or before `begin`
   const int mis = (int)((((uintptr_t)(s + begin)) & 15) / sizeof(T));
-  const int64_t vbegin = begin - mis;
-  const bool noise_vec_ok = HAS_NOISE ? ((((uintptr_t)(e + vbegin)) & 15) == 0) : true;
+  int64_t abegin = min(end, begin + ((VEC - mis) % VEC));
+  if (HAS_NOISE && (((uintptr_t)(e + abegin)) & 15) != 0) abegin = end;   // noise not co-aligned: everything per element
+  edge(begin, abegin);
 
-  for (int64_t cb = vbegin; cb < end; cb += 256 * VEC) {
-    const int64_t i0 = cb + (int64_t)tid * VEC;
-    float key[VEC];
-    bool cand[VEC];
-    const bool full = (i0 >= begin) && (i0 + VEC <= end);
-    if (full) {
-      float sc[VEC];
-      if constexpr (VEC == 4) {
-        f32x4 v = *(const f32x4*)(s + i0);
+  // ---- streaming body: whole chunks of CH elements, U independent 16-byte loads per lane issued before anything waits ----
+  typedef typename std::conditional<VEC == 4, f32x4, bf16x8>::type SV;
+  constexpr int NQ = VEC / 4;                       // noise vectors per score vector
+  struct Raw {
+    SV sc[U];
+    f32x4 en[HAS_NOISE ? U * NQ : 1];
+  };
+  // whole 16-byte vectors end at vend; a vector past it is not loaded and reads as -inf (never a candidate of a full list)
+  const int64_t vend = abegin + ((end - abegin) / VEC) * VEC;
+  auto load = [&](Raw& r, int64_t at) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sc[j] = v[j];
-      } else {
-        bf16x8 v = *(const bf16x8*)(s + i0);
+    for (int u = 0; u < U; ++u) {
+      const int64_t i0 = at + (int64_t)(u * 256 + tid) * VEC;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sc[j] = (float)v[j];
-      }
-      for (int b = 0; b < a.n_blocked; ++b) {
-        uint32_t d = blk[b] - (uint32_t)i0;
+      for (int j = 0; j < VEC; ++j) r.sc[u][j] = -INFINITY;
+      if (i0 < vend) r.sc[u] = __builtin_nontemporal_load((const SV*)(s + i0));
+    }
+    if constexpr (HAS_NOISE) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (d == (uint32_t)j) sc[j] = a.blocked_value;
-      }
-      if constexpr (HAS_NOISE) {
-        float en[VEC];
-        if (noise_vec_ok) {
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int q = 0; q < VEC / 4; ++q) {
-            f32x4 v = *(const f32x4*)(e + i0 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) en[4 * q + j] = v[j];
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) en[j] = e[i0 + j];
+        for (int q = 0; q < NQ; ++q) {
+          const int64_t i0 = at + (int64_t)(u * 256 + tid) * VEC;
+          r.en[u * NQ + q] = f32x4{1.f, 1.f, 1.f, 1.f};
+          if (i0 < vend) r.en[u * NQ + q] = __builtin_nontemporal_load((const f32x4*)(e + i0 + 4 * q));
         }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) key[j] = sc[j] / en[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) key[j] = sc[j];
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) cand[j] = !(key[j] < tau_key);
+    }
+  };
+  int64_t cb = abegin;
+  Raw cur, nxt;
+  if (PF && cb < vend) load(cur, cb);
+  for (; cb < vend; cb += CH) {
+    if constexpr (PF) {
+      if (cb + CH < vend) load(nxt, cb + CH);       // the next chunk is in flight while this one is filtered
     } else {
+      load(cur, cb);
+    }
+    float key[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const int64_t i = i0 + j;
-        const bool ok = (i >= begin) && (i < end);
-        float sc = 0.f;
-        if (ok) {
-          sc = to_f32(s[i]);
-          for (int b = 0; b < a.n_blocked; ++b)
-            if (blk[b] == (uint32_t)i) sc = a.blocked_value;
-          if constexpr (HAS_NOISE) sc = sc / e[i];
+        key[u][j] = (float)cur.sc[u][j];
+        if constexpr (HAS_NOISE) key[u][j] = key[u][j] / cur.en[u * NQ + (j >> 2)][j & 3];
+      }
+    auto index_of = [&](int k) -> int64_t { return cb + (int64_t)((k / VEC) * 256 + tid) * VEC + (k % VEC); };
+    float thr = wl.tau_key;
+    if (cb == abegin) {
+      // First chunk: the list is empty (or holds only prologue items).  The n-th largest of the 64 per-lane maxima is a
+      // valid lower bound of this chunk's n-th best key (n real elements reach it), so it filters the chunk before
+      // any item is built.  v_max drops NaNs, which only makes the bound more conservative.
+      float best = key[0][0];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) best = fmaxf(best, key[u][j]);
+      // up to n_blocked of those maxima may belong to blocked elements (whose streamed score is not their real one)
+      const int nb = n + a.n_blocked;
+      if (nb <= 64) {
+        // nb-th largest of the 64 lane values = the largest value with at least nb lanes at or above it: bitwise search on the ordered
+        // bit pattern, one v_cmp + scalar popcount per bit
+        const uint32_t ob = order_bits(best);
+        uint32_t sel = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+          const uint32_t cand = sel | (1u << bit);
+          if (__popcll(__ballot(ob >= cand)) >= nb) sel = cand;
         }
-        key[j] = sc;
-        cand[j] = ok && !(sc < tau_key);
+        const float bound = order_bits_inv(sel);
+        if (!(bound < thr)) thr = bound;
       }
     }
-    bool any = false;
+    // one v_cmp per element straight into a wave mask (SGPR pair); the masks are OR-ed on the scalar unit and per-lane
+    // candidate bits are only built for a 16-byte group in which some lane has a candidate
+    uint32_t cmask = 0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) any |= cand[j];
-    if (__ballot(any) == 0) continue;
+    for (int u = 0; u < U; ++u) {
+      bool c[VEC];
+      u64 any = 0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      u64 bal = __ballot(cand[j]);
-      if (bal == 0) continue;
-      const u64 mine = make_item(key[j], (uint32_t)(i0 + j));
-      while (bal) {
-        const int L = __ffsll((unsigned long long)bal) - 1;
-        bal &= bal - 1;
-        const u64 c = readlane64(mine, L);
-        if (c > tau) {
-          const int pos = __popcll(__ballot(item > c));  // sorted list: lanes 0..pos-1 beat c, pos < n
-          const u64 up = __shfl_up(item, 1);
-          if (lane == pos) item = c;
-          else if (lane > pos) item = up;
-          if (lane >= n) item = 0;
-          tau = readlane64(item, n - 1);
-          tau_key = order_bits_inv((uint32_t)(tau >> 32));
-          if (tau == 0) tau_key = order_bits_inv(0);
-        }
+      for (int j = 0; j < VEC; ++j) {
+        c[j] = !(key[u][j] < thr);
+        any |= __ballot(c[j]);
+      }
+      if (any) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) cmask |= c[j] ? (1u << (u * VEC + j)) : 0u;
       }
     }
+    // drain: one candidate per lane per round, re-read from memory (L1/L2 hit) so no register array is indexed dynamically
+    while (__ballot(cmask != 0)) {
+      u64 mine = 0;
+      if (cmask) {
+        const int k = __ffs(cmask) - 1;
+        cmask &= cmask - 1;
+        const int64_t i = index_of(k);
+        if (i < vend) mine = item_of(i);
+      }
+      wl.offer_lanes(mine);
+    }
+    if constexpr (PF) cur = nxt;
   }
+  edge(vend, end);
 
+  const u64 item = wl.item;
   if (lane < n) lds_items[wave * n + lane] = item;
   __syncthreads();
   const int64_t out_row = row;
