@@ -23,7 +23,8 @@ class AttnShape(ctypes.Structure):
                 ("q_sb", c_i64), ("q_sh", c_i64), ("q_sn", c_i64), ("q_sk", c_i64),
                 ("o_sb", c_i64), ("o_sh", c_i64), ("o_sn", c_i64), ("o_sk", c_i64),
                 ("t_sb", c_i64), ("t_sh", c_i64), ("t_ss", c_i64),
-                ("s_sb", c_i64), ("s_sh", c_i64), ("s_sk", c_i64)]
+                ("s_sb", c_i64), ("s_sh", c_i64), ("s_sk", c_i64),
+                ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sn", c_i64), ("dq_sk", c_i64)]
 
 
 class DiscLossShape(ctypes.Structure):
@@ -55,6 +56,11 @@ SIGNATURES = {
                                    ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_vp]),
     "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "bg_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
     "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),

@@ -1,0 +1,407 @@
+"""Fused transformer-block path: the glue between the GEMMs as hand-written kernels, gradients accumulated in place.
+
+Same mathematics as the module-by-module path of models.py (NonResidualDiscriminatorBase.py:46-90 block forward,
+NonResidualAttention.py:253-281, GPT2MLP; NeoXNonResidualBase.py:73-133), but built from four autograd Functions whose
+forward/backward launch exactly the kernels the data flow needs:
+
+  * `layer_norm` / `add_layer_norm`  - residual add + LayerNorm in one pass (bg_add_layernorm_fwd); backward gives the
+    residual gradient in fp32 AND its low-precision copy for the preceding projection, and dgamma/dbeta (bg_layernorm_bwd);
+  * `linear`  - GEMM through hipBLASLt in the compute dtype with the weight's low-precision copy cached per optimizer step;
+    backward accumulates dW (fp32) and the bias gradient (bg_bias_act_bwd, with the GELU backward folded in) straight into
+    `.grad` - no cast kernel, no AccumulateGrad add, no separate reduction;
+  * `packed_attention`  - branch / causal attention reading q, k, v as strided slices of the packed QKV projection and
+    writing dq, dk, dv straight into one packed dqkv buffer (bg_attn_shape.dq_*): no split / permute / cat copies.
+
+The residual stream and all statistics stay fp32 (what bf16 autocast computes too); `compute_dtype()` picks bf16 under
+autocast and fp32 otherwise, so the parity tests exercise the same code in fp32.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _capi as C
+from . import ops
+
+# Parameter gradients are added into `.grad` inside backward (and None is returned to autograd).  Set False to get the
+# gradients through autograd instead (torch.autograd.grad, hooks).
+ACCUMULATE_IN_PLACE = True
+# BRANCHGAN_FUSED=0 switches the models back to the module-by-module path (A/B runs, debugging)
+ENABLED = os.environ.get("BRANCHGAN_FUSED", "1") != "0"
+
+_cast_cache = {}
+_capture_epoch = 0
+_step_epoch = 0
+
+
+def _after_optimizer_step(*_):
+    """Fused / foreach optimizers update parameters through list kernels that do not always bump Tensor._version, so every
+    optimizer step also invalidates the low-precision weight copies."""
+    global _step_epoch
+    _step_epoch += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_after_optimizer_step)
+
+
+def invalidate_weights():
+    """Call after changing parameters by hand (load_state_dict, .data assignments) while a step is in flight."""
+    _after_optimizer_step()
+
+
+def begin_capture():
+    """graphs.py calls this right before a HIP-graph capture: weight copies made earlier must not be reused inside it."""
+    global _capture_epoch
+    _capture_epoch += 1
+
+
+def clear_cast_cache():
+    _cast_cache.clear()
+
+
+def compute_dtype(ref):
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return ref.dtype
+
+
+def lowp(p, dtype):
+    """The parameter in the compute dtype; one cast per parameter version (optimizer step), shared by every tree node's
+    forward and backward of that step."""
+    if p.dtype == dtype:
+        return p.detach()
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = _cast_cache.get(id(p))
+    if hit is not None and hit[0] is p and hit[1] == (p._version, p.data_ptr(), _step_epoch) and hit[2].dtype == dtype and \
+            hit[3] == capturing and (not capturing or hit[4] == _capture_epoch):
+        return hit[2]
+    t = p.detach().to(dtype)
+    _cast_cache[id(p)] = (p, (p._version, p.data_ptr(), _step_epoch), t, capturing, _capture_epoch)
+    return t
+
+
+def _grad_buffer(p):
+    """fp32 buffer the kernels accumulate into: p.grad itself when in-place accumulation is on."""
+    if ACCUMULATE_IN_PLACE and p.requires_grad:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        if p.grad.dtype == torch.float32 and p.grad.is_contiguous():
+            return p.grad, None
+    buf = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+    return buf, buf
+
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    ws = _ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 4 << 20), dtype=torch.uint8, device=device)
+        _ws[device] = ws
+    return ws
+
+
+def supported_width(C_):
+    return C_ % 8 == 0 and C_ <= 4096
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LayerNorm (+ residual add)
+# ---------------------------------------------------------------------------------------------------------------------
+def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype):
+    rows, C_ = x2.shape
+    y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    x_out = torch.empty_like(x2) if delta2 is not None else None
+    with ops._timed("add_layernorm_fwd"):
+        C.check(C.lib().bg_add_layernorm_fwd(C.ptr(x2), C.ptr(delta2), C.dtype_code(delta2) if delta2 is not None else 0, rows, C_,
+                                             C.ptr(gamma), C.ptr(beta), float(eps), C.ptr(x_out), C.ptr(y), C.dtype_code(y),
+                                             C.ptr(mean), C.ptr(rstd), C.stream_ptr()), "bg_add_layernorm_fwd")
+    return x_out, y, mean, rstd
+
+
+def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype):
+    rows, C_ = x2.shape
+    dx = torch.empty_like(x2)
+    dx_lp = torch.empty((rows, C_), dtype=lp_dtype, device=x2.device) if lp_dtype not in (None, torch.float32) else None
+    dg, dg_ret = _grad_buffer(gamma_p)
+    db, db_ret = _grad_buffer(beta_p)
+    lib = C.lib()
+    nbytes = lib.bg_layernorm_bwd_workspace_bytes(rows, C_)
+    ws = _workspace(nbytes, x2.device)
+    with ops._timed("layernorm_bwd"):
+        C.check(lib.bg_layernorm_bwd(C.ptr(dy2), C.dtype_code(dy2), C.ptr(x2), C.ptr(mean), C.ptr(rstd), C.ptr(gamma_p.detach()),
+                                     C.ptr(dres2), rows, C_, C.ptr(dx), C.ptr(dx_lp), C.dtype_code(dx_lp) if dx_lp is not None else 0,
+                                     C.ptr(dg), C.ptr(db), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
+    return dx, dx_lp, dg_ret, db_ret
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        _, y, mean, rstd = _ln_fwd(x2, None, gamma.detach(), beta.detach(), eps, out_dtype)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params = (gamma, beta)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        dx, _, dg, db = _ln_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, gamma, beta, None, None)
+        return dx.view(dy.shape), dg, db, None, None
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        d2 = delta.reshape(x2.shape).contiguous()
+        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype)
+        ctx.save_for_backward(x_out, mean, rstd)
+        ctx.params = (gamma, beta)
+        ctx.delta_dtype = delta.dtype
+        ctx.set_materialize_grads(False)
+        return x_out.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dx_new, dy):
+        x_out, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        if dy is None and dx_new is None:
+            return None, None, None, None, None, None
+        if dy is None:      # only the residual output was used
+            dres = dx_new.reshape(x_out.shape).contiguous().float()
+            return dres.view(dx_new.shape), dres.to(ctx.delta_dtype).view(dx_new.shape), None, None, None, None
+        dres2 = dx_new.reshape(x_out.shape).contiguous().float() if dx_new is not None else None
+        dx, dx_lp, dg, db = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype)
+        shape = dy.shape
+        return dx.view(shape), (dx_lp if dx_lp is not None else dx).view(shape), dg, db, None, None
+
+
+def layer_norm(x, ln, out_dtype):
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype)
+
+
+def add_layer_norm(x, delta, ln, out_dtype):
+    """-> (x + delta [fp32], LayerNorm(x + delta) [out_dtype])"""
+    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Linear (+ GELU) with in-place gradient accumulation
+# ---------------------------------------------------------------------------------------------------------------------
+_ACT = {None: 0, "gelu_tanh": 1, "gelu": 2}
+_mm_out_dtype = None       # does torch.addmm(..., out_dtype=float32, out=) accumulate a bf16 GEMM into fp32 here?  probed once
+
+
+def _probe_mm_out_dtype(device):
+    global _mm_out_dtype
+    if _mm_out_dtype is None:
+        try:
+            a = torch.ones((16, 16), dtype=torch.bfloat16, device=device)
+            g = torch.ones((16, 16), dtype=torch.float32, device=device)
+            torch.addmm(g, a, a, out_dtype=torch.float32, out=g)
+            _mm_out_dtype = bool(float(g[0, 0]) == 17.0)
+        except Exception:
+            _mm_out_dtype = False
+    return _mm_out_dtype
+
+
+def _accumulate_matmul(p, a, b):
+    """p.grad += a @ b (a, b in the compute dtype; the gradient is fp32): ONE GEMM with beta = 1 whose fp32 accumulator is
+    written out unrounded - no bf16 dW, no cast, no add."""
+    buf, ret = _grad_buffer(p)
+    if a.dtype == torch.float32:
+        buf.addmm_(a, b)
+    elif _mm_out_dtype or (_mm_out_dtype is None and not torch.cuda.is_current_stream_capturing() and _probe_mm_out_dtype(a.device)):
+        torch.addmm(buf, a, b, out_dtype=torch.float32, out=buf)
+    else:
+        buf.add_(torch.mm(a, b))
+    return ret
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x @ W + b).  layout 'io': W is (in, out) (GPT-2 Conv1D); 'oi': (out, in) (nn.Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layout, act, dtype):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != dtype:
+            x2 = x2.to(dtype)
+        w = lowp(weight, dtype)
+        wm = w if layout == "io" else w.t()
+        pre = torch.addmm(lowp(bias, dtype), x2, wm) if bias is not None else torch.mm(x2, wm)
+        if act is None:
+            y = pre
+        else:
+            y = F.gelu(pre, approximate="tanh" if act == "gelu_tanh" else "none")
+        ctx.save_for_backward(x2, pre if act is not None else None)
+        ctx.meta = (weight, bias, layout, act, dtype, x.shape)
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre = ctx.saved_tensors
+        weight, bias, layout, act, dtype, in_shape = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != dtype:
+            dy2 = dy2.to(dtype)
+        if dy2.stride(-1) != 1 or dy2.stride(0) % 4 != 0:
+            dy2 = dy2.contiguous()
+        rows, n_out = dy2.shape
+        db_ret = None
+        if bias is not None or act is not None:
+            lib = C.lib()
+            if act is not None:
+                dy2 = dy2.contiguous()
+                dpre = torch.empty_like(pre)
+            else:
+                dpre = None
+            if bias is not None:
+                db, db_ret = _grad_buffer(bias)
+            else:
+                db = torch.zeros(n_out, dtype=torch.float32, device=dy2.device)
+            ws = _workspace(lib.bg_bias_act_bwd_workspace_bytes(rows, n_out), dy2.device)
+            with ops._timed("bias_act_bwd"):
+                C.check(lib.bg_bias_act_bwd(C.ptr(dy2), C.dtype_code(dy2), rows, n_out, dy2.stride(0), _ACT[act], C.ptr(pre),
+                                            C.ptr(dpre), C.ptr(db), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_bias_act_bwd")
+            if dpre is not None:
+                dy2 = dpre
+        w = lowp(weight, dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w.t() if layout == "io" else w).view(in_shape)
+        dw_ret = _accumulate_matmul(weight, x2.t(), dy2) if layout == "io" else _accumulate_matmul(weight, dy2.t(), x2)
+        return dx, dw_ret, db_ret, None, None, None
+
+
+def linear(x, weight, bias, layout, dtype, act=None):
+    return _Linear.apply(x, weight, bias, layout, act, dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# attention on the packed QKV projection
+# ---------------------------------------------------------------------------------------------------------------------
+class _PackedAttention(torch.autograd.Function):
+    """qkv (B, T, 3, H, Dh) contiguous, T = NQ * K.  lp = None: root causal pass.  Otherwise lp carries the text KV
+    (k_text, v_text as inputs so that their gradients flow), ctx_len and paths; ancestors' (k, v) follow as inputs.
+    Returns (att (B, T, H*Dh), k (B,H,T,Dh) view, v view)."""
+
+    @staticmethod
+    def forward(ctx, qkv, k_text, v_text, spec, *anc):
+        B, T, _, H, Dh = qkv.shape
+        E = H * Dh
+        n_anc = len(anc) // 2
+        anc_k, anc_v = list(anc[:n_anc]), list(anc[n_anc:])
+        root = k_text is None
+        NQ = 1 if root else spec["n_query_nodes"]
+        K = T // NQ
+        att = torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=qkv.device)
+        q5 = qkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)          # (B,H,NQ,K,Dh) strided view
+        o5 = att.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+        kview = qkv[:, :, 1].permute(0, 2, 1, 3)                                # (B,H,T,Dh)
+        vview = qkv[:, :, 2].permute(0, 2, 1, 3)
+        if root:
+            kt, vt = kview, vview
+            ctx_len = ops.causal_ctx_len(T, T, qkv.device)
+            slots_k, slots_v, paths = [], [], [[]]
+        else:
+            kt, vt, ctx_len, paths = k_text, v_text, spec["ctx_len"], spec["paths"]
+            if kt.stride() != vt.stride() or kt.stride(-1) != 1:
+                kt, vt = kt.contiguous(), vt.contiguous()
+            own_k = [kview[:, :, n * K:(n + 1) * K] for n in range(NQ)]
+            own_v = [vview[:, :, n * K:(n + 1) * K] for n in range(NQ)]
+            ref = own_k[0].stride()
+            if any(t.stride() != ref for t in anc_k + anc_v):
+                raise NotImplementedError("ancestor KV slots must share the packed-QKV layout of the new tokens")
+            slots_k, slots_v = anc_k + own_k, anc_v + own_v
+        path, path_len, max_path = ops.path_tables(paths, qkv.device)
+        sh = ops._attn_shape(q5, kt, slots_k, spec["scale"], max_path, o5)
+        with ops._timed("branch_attn_fwd"):
+            C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
+                                               ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
+                                               C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        ctx.save_for_backward(qkv, att, lse, ctx_len, path, path_len, *([] if root else [kt, vt]), *anc_k, *anc_v)
+        ctx.meta = (root, NQ, K, n_anc, spec["scale"], max_path)
+        ctx.set_materialize_grads(False)
+        return att.view(B, T, E), kview, vview
+
+    @staticmethod
+    def backward(ctx, datt, dk_out, dv_out):
+        root, NQ, K, n_anc, scale, max_path = ctx.meta
+        saved = ctx.saved_tensors
+        qkv, att, lse, ctx_len, path, path_len = saved[:6]
+        rest = list(saved[6:])
+        B, T, _, H, Dh = qkv.shape
+        dev, dt = qkv.device, qkv.dtype
+        dqkv = torch.empty_like(qkv)
+        q5 = qkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+        o5 = att.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+        dq5 = dqkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+        kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+        dkview, dvview = dqkv[:, :, 1].permute(0, 2, 1, 3), dqkv[:, :, 2].permute(0, 2, 1, 3)
+        if datt is None:
+            datt = torch.zeros((B, T, H, Dh), dtype=dt, device=dev)
+        do5 = datt.reshape(B, T, H, Dh)
+        if do5.dtype != dt:
+            do5 = do5.to(dt)
+        if not do5.is_contiguous():
+            do5 = do5.contiguous()
+        do5 = do5.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+        d_anc_k, d_anc_v = [], []
+        if root:
+            kt, vt = kview, vview
+            dkt, dvt = dkview, dvview
+            slots_k, slots_v, dsk, dsv = [], [], [], []
+        else:
+            kt, vt = rest[0], rest[1]
+            anc_k, anc_v = rest[2:2 + n_anc], rest[2 + n_anc:]
+            S = kt.shape[2]
+            if kt.stride() == (S * 3 * H * Dh, Dh, 3 * H * Dh, 1):          # slices of the root's packed QKV
+                dtext = torch.empty((B, S, 3, H, Dh), dtype=dt, device=dev)
+                dkt, dvt = dtext[:, :, 1].permute(0, 2, 1, 3), dtext[:, :, 2].permute(0, 2, 1, 3)
+            else:
+                dkt = torch.empty_strided(kt.shape, kt.stride(), dtype=dt, device=dev)
+                dvt = torch.empty_strided(kt.shape, kt.stride(), dtype=dt, device=dev)
+            for _ in range(n_anc):
+                buf = torch.empty((B, K, 3, H, Dh), dtype=dt, device=dev)
+                d_anc_k.append(buf[:, :, 1].permute(0, 2, 1, 3))
+                d_anc_v.append(buf[:, :, 2].permute(0, 2, 1, 3))
+            own = lambda t: [t[:, :, n * K:(n + 1) * K] for n in range(NQ)]
+            slots_k, slots_v = list(anc_k) + own(kview), list(anc_v) + own(vview)
+            dsk, dsv = d_anc_k + own(dkview), d_anc_v + own(dvview)
+        delta = torch.empty_like(lse)
+        sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+        sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
+        with ops._timed("branch_attn_bwd"):
+            C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
+                                               ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
+                                               C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), ops._ptr_array(dsk),
+                                               ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+        if dk_out is not None:      # what the descendants' attention sent back to this node's keys / values
+            dkview.add_(dk_out)
+        if dv_out is not None:
+            dvview.add_(dv_out)
+        if root:
+            return (dqkv, None, None, None)
+        return (dqkv, dkt, dvt, None, *d_anc_k, *d_anc_v)
+
+
+def packed_attention(qkv, lp, scale):
+    """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views)."""
+    if lp is None:
+        att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale)})
+    else:
+        spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes}
+        anc_k = [a[0] for a in lp.ancestors]
+        anc_v = [a[1] for a in lp.ancestors]
+        att, k, v = _PackedAttention.apply(qkv, lp.text[0], lp.text[1], spec, *anc_k, *anc_v)
+    return att, (k, v)

@@ -12,6 +12,7 @@ import copy
 import torch
 
 from . import ops
+from . import fused
 
 
 class GraphedTrainStep:
@@ -40,6 +41,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
         self.graph = torch.cuda.CUDAGraph()
+        fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
         with torch.cuda.graph(self.graph):
             self.losses = self._forward_backward()
         ops.TIMING = timing

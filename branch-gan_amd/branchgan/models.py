@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import ops
+from . import fused, ops
 from .configs import LMConfig
 
 _IGNORED_BUFFERS = (".attention.bias", ".attention.self_bias", ".attention.masked_bias", ".attn.bias", ".attn.self_bias",
@@ -268,6 +268,21 @@ def _layer_past(textualPast, i):
     return textualPast.layer(i) if isinstance(textualPast, BranchPast) else textualPast[i]
 
 
+def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate=None):
+    """The fused block path (branchgan.fused) covers the training hot path: fp32 parameters on the GPU (bf16 compute comes
+    from autocast), no dropout, engine-form past.  Everything else runs module by module."""
+    cfg = model.config
+    if not fused.ENABLED or not input_ids.is_cuda or output_hidden_states or customCasualMask is not None:
+        return False
+    if textualPast is not None and not isinstance(textualPast, BranchPast):
+        return False
+    if dropoutRate or cfg.resid_pdrop or cfg.embd_pdrop or cfg.attn_pdrop:
+        return False
+    if not fused.supported_width(cfg.hidden_size) or cfg.head_dim not in (32, 64, 128, 256):
+        return False
+    return next(model.parameters()).dtype == torch.float32
+
+
 class GPTNeoXForCausalLM(_LMBase):
     """NeoXNonResidualBase.py:303-400: LM head `embed_out` or 1-unit `valueHead`, chosen by returnLmLogits."""
 
@@ -401,6 +416,22 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
+    def fused_forward(self, x, delta, dtype, lp):
+        """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
+        block's MLP output, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel."""
+        at = self.attn
+        B, T, _ = x.shape
+        if delta is None:
+            x1, h1 = x, fused.layer_norm(x, self.ln_1, dtype)
+        else:
+            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype)
+        qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
+        a, present = fused.packed_attention(qkv, lp, at._scale())
+        a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype)
+        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype)
+        g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh")
+        return x2, fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), present
+
 
 class NonResidualGPT2Model(_LMBase):
     def __init__(self, config):
@@ -436,6 +467,18 @@ class NonResidualGPT2LMHeadModel(_LMBase):
         pos = _positions(position_ids, B, T, input_ids.device)
         branch = textualPast is not None
         tr = self.transformer
+        if _fused_eligible(self, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate):
+            dtype = fused.compute_dtype(tr.wte.weight)
+            with torch.autocast("cuda", enabled=False):
+                x, delta, presents = tr.wte(input_ids) + tr.wpe(pos.long()), None, []
+                for i, block in enumerate(tr.h):
+                    x, delta, present = block.fused_forward(x, delta, dtype, _layer_past(textualPast, i) if branch else None)
+                    presents.append(present)
+                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype)
+                head = self.lm_head if returnLmLogits else self.valueHead
+                logits = fused.linear(y, head.weight, None, "oi", dtype)
+            return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,
+                                   hidden_states=None, attentions=None, cross_attentions=None, last_hidden_state=y)
         x = tr.wte(input_ids) + tr.wpe(pos.long())
         p = dropoutRate if dropoutRate is not None else self.config.embd_pdrop
         if p:

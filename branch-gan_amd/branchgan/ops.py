@@ -282,14 +282,19 @@ def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=N
 _arange_cache = {}
 
 
-def causal_attention(q, k, v, scale=None):
-    """Root causal pass as the same kernel: query i sees keys j <= i + (S - T).  q (B,H,T,Dh), k/v (B,H,S,Dh)."""
-    T_, S_ = q.shape[2], k.shape[2]
-    key = (T_, S_, str(q.device))
+def causal_ctx_len(T_, S_, device):
+    """ctx_len of the root causal pass (query i sees keys j <= i + S - T), cached per device."""
+    key = (T_, S_, str(device))
     ctx = _arange_cache.get(key)
     if ctx is None:
-        ctx = torch.arange(S_ - T_ + 1, S_ + 1, dtype=torch.int32, device=q.device)
+        ctx = torch.arange(S_ - T_ + 1, S_ + 1, dtype=torch.int32, device=device)
         _arange_cache[key] = ctx
+    return ctx
+
+
+def causal_attention(q, k, v, scale=None):
+    """Root causal pass as the same kernel: query i sees keys j <= i + (S - T).  q (B,H,T,Dh), k/v (B,H,S,Dh)."""
+    ctx = causal_ctx_len(q.shape[2], k.shape[2], q.device)
     out, lse = branch_attention(q, k, v, ctx, (), (), paths=[[]], scale=scale)
     return out, lse
 

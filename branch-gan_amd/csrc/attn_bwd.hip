@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
       axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
     }
   }
-  store_rowvec<T, DH>(dq, 1.f, (T*)a.dq + ooff, h, valid);
+  const int64_t dqoff = (int64_t)b * sh.dq_sb + (int64_t)hh * sh.dq_sh + (int64_t)n * sh.dq_sn + (int64_t)kq * sh.dq_sk;
+  store_rowvec<T, DH>(dq, 1.f, (T*)a.dq + dqoff, h, valid);
 }
 
 static size_t attn_dq_lds_bytes(int dtype, int Dh) {
@@ -373,6 +374,14 @@ extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, con
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.sh = *shape;
+  if (!(a.sh.dq_sb | a.sh.dq_sh | a.sh.dq_sn | a.sh.dq_sk)) {
+    a.sh.dq_sb = a.sh.o_sb; a.sh.dq_sh = a.sh.o_sh; a.sh.dq_sn = a.sh.o_sn; a.sh.dq_sk = a.sh.o_sk;
+  }
+  {
+    const int64_t al = (a.sh.dtype == BG_F32) ? 4 : 8;
+    const int64_t dqs[] = {a.sh.dq_sb, a.sh.dq_sh, a.sh.dq_sn, a.sh.dq_sk};
+    for (int64_t v : dqs) BG_REQUIRE(v >= 0 && v % al == 0, "%s: dq stride %lld is not a multiple of %lld elements", who, (long long)v, (long long)al);
+  }
   a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
   a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse); a.dout = dout;
   a.dq = dq; a.dk_text = dk_text; a.dv_text = dv_text; a.delta = delta;

@@ -1,0 +1,425 @@
+// Row-wise glue of the transformer block between the GEMMs, fused so that each activation crosses HBM once.
+//
+// The reference builds these from separate ATen ops per block and per tree node (Models/GPT2BranchAttention/
+// NonResidualDiscriminatorBase.py:46-90 block forward: ln_1 / residual add / ln_2 / MLP; NeoXNonResidualBase.py:73-133),
+// and autograd adds one kernel per cast, residual add, bias-gradient reduction and LayerNorm-parameter reduction.
+// See include/branchgan.h: bg_add_layernorm_fwd, bg_layernorm_bwd, bg_bias_act_bwd.
+//
+// All three are HBM-bound streaming kernels: one wave per row (LayerNorm) or one thread per 4 columns (bias/activation),
+// 16-byte loads, fp32 arithmetic, residual stream and statistics in fp32, activations in fp32 or bf16.
+// Column reductions (dgamma, dbeta, dbias) are deterministic: per-workgroup partials in the caller's workspace, then a
+// second small kernel adds them in a fixed order into the fp32 gradient (accumulating: grad += sum).
+#include "common.h"
+
+namespace bg {
+
+#define LN_MAX_NV 16   // 16-byte fp32 vectors per lane: C <= 64 * 4 * 16 = 4096
+
+template <typename T> struct V4;
+template <> struct V4<float> {
+  typedef f32x4 type;
+};
+template <> struct V4<bf16_t> {
+  typedef bf16x4 type;
+};
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&v)[4]) {
+  typename V4<T>::type raw = *(const typename V4<T>::type*)p;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (float)raw[j];
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
+  typename V4<T>::type raw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) raw[j] = from_f32<T>(v[j]);
+  *(typename V4<T>::type*)p = raw;
+}
+
+struct LnFwdArgs {
+  const float* x;
+  const void* delta;
+  const float* gamma;
+  const float* beta;
+  float* x_out;
+  void* y;
+  float* mean;
+  float* rstd;
+  int64_t rows;
+  int C;
+  float eps;
+};
+
+// TD: dtype of delta (ignored when delta == nullptr), TY: dtype of y
+template <typename TD, typename TY, int NV>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= a.rows) return;
+  const int C = a.C;
+  const float* x = a.x + r * C;
+  const TD* d = a.delta ? (const TD*)a.delta + r * C : nullptr;
+  float v[NV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = 0.f;
+    if (c < C) {
+      load4<float>(x + c, v[i]);
+      if (d) {
+        float dv[4];
+        load4<TD>(d + c, dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
+        store4<float>(a.x_out + r * C + c, v[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < C) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = v[i][j] - mean;
+        q += t * t;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + a.eps);
+  if (lane == 0) {
+    a.mean[r] = mean;
+    a.rstd[r] = rstd;
+  }
+  TY* y = (TY*)a.y + r * C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < C) {
+      float g[4], b[4], o[4];
+      load4<float>(a.gamma + c, g);
+      load4<float>(a.beta + c, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      store4<TY>(y + c, o);
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const void* dy;
+  const float* x;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* dres;
+  float* dx;
+  void* dx_lp;
+  float* partial;   // [gridDim.x][2][C]
+  int64_t rows;
+  int C;
+};
+
+// TY: dtype of dy;  TL: dtype of the low-precision copy of dx (ignored when dx_lp == nullptr)
+template <typename TY, typename TL, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
+  extern __shared__ float lds[];   // [2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C;
+  const float inv_c = 1.0f / (float)C;
+  float gam[NV][4], dg[NV][4], db[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gam[i][j] = dg[i][j] = db[i][j] = 0.f;
+    if (c < C) load4<float>(a.gamma + c, gam[i]);
+  }
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < a.rows; r += (int64_t)gridDim.x * 4) {
+    const float mean = a.mean[r], rstd = a.rstd[r];
+    const float* x = a.x + r * C;
+    const TY* dy = (const TY*)a.dy + r * C;
+    float xh[NV][4], g[NV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xh[i][j] = g[i][j] = 0.f;
+      if (c < C) {
+        float xv[4], dv[4];
+        load4<float>(x + c, xv);
+        load4<TY>(dy + c, dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * gam[i][j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+          dg[i][j] += dv[j] * xh[i][j];
+          db[i][j] += dv[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_c;
+    s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < C) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2);
+        if (a.dres) {
+          float rv[4];
+          load4<float>(a.dres + r * C + c, rv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += rv[j];
+        }
+        store4<float>(a.dx + r * C + c, o);
+        if (a.dx_lp) store4<TL>((TL*)a.dx_lp + r * C + c, o);
+      }
+    }
+  }
+  // the four waves' column partials, added in wave order
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < C) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (w == 0) {
+              lds[c + j] = dg[i][j];
+              lds[C + c + j] = db[i][j];
+            } else {
+              lds[c + j] += dg[i][j];
+              lds[C + c + j] += db[i][j];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* part = a.partial + (int64_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) part[c] = lds[c];
+}
+
+// out0[c] += sum_g partial[g][c] (c < n0), out1[c - n0] += ... (n0 <= c < n0 + n1).  256 threads = 32 columns x 8 slices of
+// g; every thread adds its slice in increasing g, then the 8 slice sums are added in slice order: a fixed summation order.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int G, int n0, int n1, float* out0, float* out1) {
+  __shared__ float red[8][33];
+  const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + col;
+  const int n = n0 + n1;
+  float s = 0.f;
+  if (c < n) {
+#pragma unroll 8
+    for (int g = slice; g < G; g += 8) s += partial[(int64_t)g * n + c];
+  }
+  red[slice][col] = s;
+  __syncthreads();
+  if (slice == 0 && c < n) {
+    float t = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][col];
+    if (c < n0) out0[c] += t;
+    else out1[c - n0] += t;
+  }
+}
+
+// ---- bias gradient (column sums) with the activation's backward in the same pass ------------------------------------------
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k = 0.7978845608028654f, c = 0.044715f;
+  const float u = k * (x + c * x * x * x);
+  const float t = 1.f - 2.f / (__expf(2.f * u) + 1.f);     // tanh(u); exp overflow -> 1, underflow -> -1
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k * (1.f + 3.f * c * x * x);
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.7071067811865476f));
+  return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+struct BiasActArgs {
+  const void* dy;
+  const void* pre;
+  void* dx;
+  float* partial;   // [gridDim.x][C]
+  int64_t rows, dy_stride;
+  int C;
+};
+
+// MODE 0: column sums of dy only;  1: dx = dy * gelu_tanh'(pre);  2: dx = dy * gelu_erf'(pre); sums of dx
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(BiasActArgs a) {
+  const int C = a.C;
+  const int G = gridDim.x;
+  float* part = a.partial + (int64_t)blockIdx.x * C;
+  const int c = 4 * (blockIdx.y * 256 + threadIdx.x);      // grid.y column chunks of 1024
+  if (c < C) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int64_t r = blockIdx.x; r < a.rows; r += G) {
+      float d[4];
+      load4<T>((const T*)a.dy + r * a.dy_stride + c, d);
+      if constexpr (MODE != 0) {
+        float p[4];
+        load4<T>((const T*)a.pre + r * C + c, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] *= (MODE == 1) ? gelu_tanh_grad(p[j]) : gelu_erf_grad(p[j]);
+        store4<T>((T*)a.dx + r * C + c, d);
+        // the bias gradient is the sum of the ROUNDED values the next GEMM sees, like autograd's sum over dx
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = to_f32(from_f32<T>(d[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += d[j];
+    }
+    store4<float>(part + c, acc);
+  }
+}
+
+static int ln_groups(int64_t rows) {       // one row per wave up to 128 workgroups, then several rows per wave
+  int64_t g = cdiv(rows, 4);
+  return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+}
+static int bias_groups(int64_t rows) {
+  int64_t g = cdiv(rows, 8);
+  return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+}
+
+template <typename TD, typename TY>
+static void launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(a.rows, 4)), block(256);
+  const int nv = (int)cdiv(a.C, 256);
+  if (nv <= 2) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 2>), grid, block, 0, st, a);
+  else if (nv <= 4) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 4>), grid, block, 0, st, a);
+  else if (nv <= 8) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 8>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 16>), grid, block, 0, st, a);
+}
+
+template <typename TY, typename TL>
+static void launch_ln_bwd(const LnBwdArgs& a, int G, hipStream_t st) {
+  dim3 grid((unsigned)G), block(256);
+  const size_t lds = (size_t)2 * a.C * sizeof(float);
+  const int nv = (int)cdiv(a.C, 256);
+  if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2>), grid, block, lds, st, a);
+  else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4>), grid, block, lds, st, a);
+  else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 8>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 16>), grid, block, lds, st, a);
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+static bool dtype_ok(int d) { return d == BG_F32 || d == BG_BF16; }
+static bool al16(const void* p) { return p && (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C, const float* gamma,
+                                    const float* beta, float eps, float* x_out, void* y, int y_dtype, float* mean, float* rstd,
+                                    void* stream) {
+  BG_REQUIRE(x && gamma && beta && y && mean && rstd, "bg_add_layernorm_fwd: null argument");
+  BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_add_layernorm_fwd: rows=%lld", (long long)rows);
+  BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_add_layernorm_fwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
+  BG_REQUIRE(dtype_ok(y_dtype) && (!delta || dtype_ok(delta_dtype)), "bg_add_layernorm_fwd: dtype");
+  BG_REQUIRE(!delta || x_out, "bg_add_layernorm_fwd: delta without x_out");
+  BG_REQUIRE(al16(x) && al16(gamma) && al16(beta) && (!delta || (((uintptr_t)delta) & 7) == 0) && (!delta || al16(x_out)) && (((uintptr_t)y) & 7) == 0,
+             "bg_add_layernorm_fwd: pointers must be 16-byte aligned (8 for bf16)");
+  LnFwdArgs a{x, delta, gamma, beta, x_out, y, mean, rstd, rows, C, eps};
+  hipStream_t st = (hipStream_t)stream;
+  const bool dbf = delta && delta_dtype == BG_BF16;
+  if (y_dtype == BG_BF16) {
+    if (dbf) launch_ln_fwd<bf16_t, bf16_t>(a, st);
+    else launch_ln_fwd<float, bf16_t>(a, st);
+  } else {
+    if (dbf) launch_ln_fwd<bf16_t, float>(a, st);
+    else launch_ln_fwd<float, float>(a, st);
+  }
+  BG_CHECK_LAUNCH("bg_add_layernorm_fwd");
+  return BG_OK;
+}
+
+extern "C" size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)ln_groups(rows) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                                float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  BG_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "bg_layernorm_bwd: null argument");
+  BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_layernorm_bwd: rows=%lld", (long long)rows);
+  BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_layernorm_bwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
+  BG_REQUIRE(dtype_ok(dy_dtype) && (!dx_lp || dtype_ok(lp_dtype)), "bg_layernorm_bwd: dtype");
+  BG_REQUIRE(al16(x) && al16(gamma) && al16(dx) && (!dres || al16(dres)) && (((uintptr_t)dy) & 7) == 0 && (((uintptr_t)dx_lp) & 7) == 0,
+             "bg_layernorm_bwd: pointers must be 16-byte aligned (8 for bf16)");
+  const size_t need = bg_layernorm_bwd_workspace_bytes(rows, C);
+  if (!workspace || workspace_bytes < need || !al16(workspace)) {
+    set_error("bg_layernorm_bwd: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
+    return BG_ERR_WORKSPACE;
+  }
+  const int G = ln_groups(rows);
+  LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, dx_lp, (float*)workspace, rows, C};
+  hipStream_t st = (hipStream_t)stream;
+  const bool lbf = dx_lp && lp_dtype == BG_BF16;
+  if (dy_dtype == BG_BF16) {
+    if (lbf) launch_ln_bwd<bf16_t, bf16_t>(a, G, st);
+    else launch_ln_bwd<bf16_t, float>(a, G, st);
+  } else {
+    if (lbf) launch_ln_bwd<float, bf16_t>(a, G, st);
+    else launch_ln_bwd<float, float>(a, G, st);
+  }
+  BG_CHECK_LAUNCH("bg_layernorm_bwd");
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, C, dgamma, dbeta);
+  BG_CHECK_LAUNCH("bg_layernorm_bwd(reduce)");
+  return BG_OK;
+}
+
+extern "C" size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)bias_groups(rows) * (size_t)C * sizeof(float);
+}
+
+extern "C" int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride, int act, const void* pre, void* dx,
+                               float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  BG_REQUIRE(dy && dbias, "bg_bias_act_bwd: null dy/dbias");
+  BG_REQUIRE(dtype_ok(dtype), "bg_bias_act_bwd: dtype %d", dtype);
+  BG_REQUIRE(rows > 0 && rows < (1ll << 31) && C > 0 && C % 4 == 0 && dy_row_stride >= C && dy_row_stride % 4 == 0,
+             "bg_bias_act_bwd: rows=%lld C=%d stride=%lld (C and the stride must be multiples of 4)", (long long)rows, C, (long long)dy_row_stride);
+  BG_REQUIRE(act >= 0 && act <= 2, "bg_bias_act_bwd: act=%d (0 none, 1 gelu-tanh, 2 gelu-erf)", act);
+  BG_REQUIRE(act == 0 || (pre && dx && dy_row_stride == C), "bg_bias_act_bwd: an activation needs pre, dx and contiguous dy");
+  const uintptr_t am = dtype == BG_F32 ? 15 : 7;
+  BG_REQUIRE((((uintptr_t)dy) & am) == 0 && (((uintptr_t)pre) & am) == 0 && (((uintptr_t)dx) & am) == 0, "bg_bias_act_bwd: misaligned pointer");
+  const size_t need = bg_bias_act_bwd_workspace_bytes(rows, C);
+  if (!workspace || workspace_bytes < need || !al16(workspace)) {
+    set_error("bg_bias_act_bwd: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
+    return BG_ERR_WORKSPACE;
+  }
+  const int G = bias_groups(rows);
+  BiasActArgs a{dy, pre, dx, (float*)workspace, rows, dy_row_stride, C};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)G, (unsigned)cdiv(C, 1024)), block(256);
+#define BG_LAUNCH_BA(T)                                                                             \
+  do {                                                                                              \
+    if (act == 0) hipLaunchKernelGGL((bias_act_bwd_kernel<T, 0>), grid, block, 0, st, a);           \
+    else if (act == 1) hipLaunchKernelGGL((bias_act_bwd_kernel<T, 1>), grid, block, 0, st, a);      \
+    else hipLaunchKernelGGL((bias_act_bwd_kernel<T, 2>), grid, block, 0, st, a);                    \
+  } while (0)
+  if (dtype == BG_F32) BG_LAUNCH_BA(float);
+  else BG_LAUNCH_BA(bf16_t);
+#undef BG_LAUNCH_BA
+  BG_CHECK_LAUNCH("bg_bias_act_bwd");
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, 0, dbias, (float*)nullptr);
+  BG_CHECK_LAUNCH("bg_bias_act_bwd(reduce)");
+  return BG_OK;
+}

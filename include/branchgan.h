@@ -104,7 +104,8 @@ int bg_softmax_stats_bwd(const void* logits, int dtype, int64_t rows, int64_t V,
  * softmax over that set with scores scale * <q, key>; out = sum w * value; lse = log-sum-exp (fp32).
  *
  * Layouts (element strides; feature dim Dh contiguous):
- *   q, out, dout, dq : [b][h][n][k][Dh]  strides (q_sb, q_sh, q_sn, q_sk)
+ *   q                : [b][h][n][k][Dh]  strides (q_sb, q_sh, q_sn, q_sk)
+ *   out, dout        : same index space, strides (o_sb, o_sh, o_sn, o_sk);  dq: (dq_*) or, when those are 0, (o_*)
  *   k_text, v_text   : [b][h][s][Dh]     strides (t_sb, t_sh, t_ss)         S_text rows
  *   slots            : host arrays of n_slots device pointers, each [b][h][k][Dh] strides (s_sb, s_sh, s_sk)
  *   ctx_len          : int32 [K];  path: int32 [NQ][max_path] slot indices;  path_len: int32 [NQ]
@@ -119,9 +120,11 @@ typedef struct {
   int n_slots, max_path;
   float scale;
   int64_t q_sb, q_sh, q_sn, q_sk;
-  int64_t o_sb, o_sh, o_sn, o_sk;     /* out / dout / dq share these */
+  int64_t o_sb, o_sh, o_sn, o_sk;     /* out / dout (and dq unless dq_* are set) */
   int64_t t_sb, t_sh, t_ss;           /* k_text, v_text (and dk_text, dv_text) */
   int64_t s_sb, s_sh, s_sk;           /* every slot tensor (and its gradient) */
+  int64_t dq_sb, dq_sh, dq_sn, dq_sk; /* backward only: strides of dq; all zero = the o_* strides.  Lets dq, dk, dv land in
+                                         one packed dqkv buffer (the layout q, k, v were sliced from) with no gather */
 } bg_attn_shape;
 
 int bg_branch_attn_fwd(const bg_attn_shape* shape,
@@ -152,6 +155,36 @@ int bg_neox_qkv_rope_fwd(const void* qkv, int dtype, int B, int T, int H, int Dh
 int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dtype, int B, int T, int H, int Dh, int rot,
                          const float* cos_tab, const float* sin_tab, int max_pos, const int32_t* position_ids,
                          void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise glue of the transformer block, fused around the GEMMs (residual stream and statistics fp32,
+ * activations fp32 or bf16).  Replaces, per block and per tree node, the ATen chains of
+ * Models/GPT2BranchAttention/NonResidualDiscriminatorBase.py:46-90 (ln_1, residual add, ln_2) and
+ * Models/NeoXBranchAttention/NeoXNonResidualBase.py:108-133, and in backward the separate cast, residual-add,
+ * LayerNorm dgamma/dbeta and bias-gradient reductions autograd launches for them.
+ *
+ * bg_add_layernorm_fwd:  xn = x + delta (delta may be NULL: xn = x, x_out untouched);  x_out = xn;
+ *   y = (xn - mean) * rstd * gamma + beta, mean / rstd per row (biased variance, eps inside the root).
+ *   x, x_out fp32 [rows][C]; delta [rows][C] of delta_dtype; y [rows][C] of y_dtype; mean, rstd fp32 [rows].
+ * bg_layernorm_bwd:  dx = dres + LayerNorm'(dy) (dres may be NULL); dx_lp (optional) = dx rounded to lp_dtype
+ *   (the gradient the preceding projection's GEMMs consume);  dgamma += sum_r dy * xhat;  dbeta += sum_r dy.
+ * bg_bias_act_bwd:  act 0: dbias += column sums of dy [rows][C] (row stride dy_row_stride);
+ *   act 1 / 2: dx = dy * gelu'(pre) (tanh / erf form), dbias += column sums of dx.
+ * C % 4 == 0; LayerNorm: C <= 4096.  The column reductions are deterministic (per-workgroup partials in the
+ * workspace, added in a fixed order) and ACCUMULATE into the fp32 gradients.
+ */
+int bg_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C,
+                         const float* gamma, const float* beta, float eps,
+                         float* x_out, void* y, int y_dtype, float* mean, float* rstd, void* stream);
+size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
+int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, const float* dres, int64_t rows, int C,
+                     float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C);
+int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride,
+                    int act, const void* pre, void* dx, float* dbias,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused discriminator losses.  Replaces Models/Losses/DiscriminatorLoss.py:4-74 (≈60 ATen launches).

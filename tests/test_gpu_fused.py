@@ -1,0 +1,162 @@
+"""GPU parity of the fused block glue (bg_add_layernorm_fwd / bg_layernorm_bwd / bg_bias_act_bwd, packed attention with
+dq strides) against plain PyTorch fp32 references of the same ops, and of the fused GPT-2 block path against the
+module-by-module path of the same model (which tests/test_gpu_tree.py pins to the reference's goldens).
+Tolerances: fp32 kernels 2e-5 abs on O(1) values (reduction order differs); bf16 outputs half a bf16 ulp (2^-8 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,C", [(37, 64), (256, 768), (1024, 2048), (5, 4096)])
+@pytest.mark.parametrize("lowp", [False, True])
+def test_add_layernorm_fwd_bwd(rows, C, lowp):
+    from branchgan import fused
+    fused.ACCUMULATE_IN_PLACE = True
+    torch.manual_seed(rows + C)
+    dt = torch.bfloat16 if lowp else torch.float32
+    x = torch.randn(rows, C, device="cuda", requires_grad=True)
+    delta = torch.randn(rows, C, device="cuda").to(dt).requires_grad_(True)
+    ln = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0.0, 0.2)
+    ln.weight.grad = torch.full_like(ln.weight, 0.5)          # the kernel accumulates
+    ln.bias.grad = torch.full_like(ln.bias, -0.25)
+    x_new, y = fused.add_layer_norm(x, delta, ln, dt)
+    gx, gy = torch.randn_like(x_new), torch.randn(rows, C, device="cuda").to(dt)
+    torch.autograd.backward([x_new, y], [gx, gy])
+    dgam, dbet = ln.weight.grad.clone(), ln.bias.grad.clone()
+
+    xr, dr = x.detach().clone().requires_grad_(True), delta.detach().float().requires_grad_(True)
+    lr = torch.nn.LayerNorm(C).cuda()
+    lr.load_state_dict(ln.state_dict())
+    xs = xr + dr
+    yr = lr(xs)
+    torch.autograd.backward([xs, yr], [gx, gy.float()])
+    assert torch.allclose(x_new, xs, atol=1e-6)
+    tol = dict(atol=2e-2, rtol=2 ** -7) if lowp else dict(atol=2e-5, rtol=1e-5)
+    assert torch.allclose(y.float(), yr, **tol)
+    assert torch.allclose(x.grad, xr.grad, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(delta.grad.float(), dr.grad, **(dict(atol=3e-2, rtol=2 ** -7) if lowp else dict(atol=2e-4, rtol=1e-4)))
+    scale = rows ** 0.5
+    assert torch.allclose(dgam - 0.5, lr.weight.grad, atol=2e-4 * scale, rtol=1e-4)
+    assert torch.allclose(dbet + 0.25, lr.bias.grad, atol=2e-4 * scale, rtol=1e-4)
+
+    # plain LayerNorm (no residual input) through the same kernels
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = fused.layer_norm(x2, ln, dt)
+    y2.backward(gy)
+    x3 = x.detach().clone().requires_grad_(True)
+    lr(x3).backward(gy.float())
+    assert torch.allclose(x2.grad, x3.grad, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,n_out", [(33, 64), (256, 3072), (2048, 2304)])
+@pytest.mark.parametrize("act", [None, "gelu_tanh", "gelu"])
+@pytest.mark.parametrize("lowp", [False, True])
+def test_linear_bias_act(rows, n_out, act, lowp):
+    from branchgan import fused
+    fused.ACCUMULATE_IN_PLACE = True
+    torch.manual_seed(rows + n_out)
+    dt = torch.bfloat16 if lowp else torch.float32
+    n_in = 96
+    x = (0.5 * torch.randn(rows, n_in, device="cuda")).to(dt).requires_grad_(True)
+    w = torch.nn.Parameter(0.1 * torch.randn(n_in, n_out, device="cuda"))
+    b = torch.nn.Parameter(0.1 * torch.randn(n_out, device="cuda"))
+    y = fused.linear(x, w, b, "io", dt, act=act)
+    gy = torch.randn(rows, n_out, device="cuda").to(dt)
+    y.backward(gy)
+
+    xr = x.detach().float().requires_grad_(True)
+    wr, br = w.detach().to(dt).float().requires_grad_(True), b.detach().to(dt).float().requires_grad_(True)
+    pre = xr @ wr + br
+    if lowp:
+        pre = pre.to(dt).float()
+    yr = pre if act is None else F.gelu(pre, approximate="tanh" if act == "gelu_tanh" else "none")
+    yr.backward(gy.float())
+    tol = dict(atol=3e-2, rtol=2 ** -6) if lowp else dict(atol=5e-5, rtol=1e-4)
+    assert torch.allclose(y.float(), yr, **tol)
+    assert torch.allclose(x.grad.float(), xr.grad, **tol)
+    gt = dict(atol=(0.15 if lowp else 2e-4) * rows ** 0.5, rtol=2e-2 if lowp else 1e-4)
+    assert torch.allclose(w.grad, wr.grad, **gt)
+    assert torch.allclose(b.grad, br.grad, **gt)
+
+
+def _gpt2(hidden=64, heads=2, layers=2):
+    from branchgan import configs, models
+    cfg = configs.LMConfig("gpt2", 97, hidden, layers, heads, 64)
+    torch.manual_seed(0)
+    return models.NonResidualGPT2LMHeadModel(cfg).cuda()
+
+
+@pytest.mark.parametrize("lm_head", [True, False])
+def test_fused_gpt2_matches_modules(lm_head):
+    """Root pass + one chain branch step + a 3-node one-pass tree, loss over everything; logits and every gradient of the
+    fused path against the module-by-module path (fp32)."""
+    from branchgan import fused, models
+    model = _gpt2()
+    B, S, K = 3, 24, 5
+    ids = torch.randint(0, 97, (B, S), device="cuda")
+    sparse = torch.tensor([2, 7, 11, 12, 20], device="cuda")
+    ctx_len = (sparse + 1).to(torch.int32)
+    b_ids = torch.randint(0, 97, (B, K), device="cuda")
+    t_ids = torch.randint(0, 97, (B, 3 * K), device="cuda")
+
+    def run(enabled):
+        fused.ENABLED = enabled
+        model.zero_grad(set_to_none=True)
+        L = len(model.transformer.h)
+        out = model(input_ids=ids, use_cache=True, returnLmLogits=lm_head)
+        text = [out.past_key_values[l] for l in range(L)]
+        pos1 = (sparse + 1).to(torch.int32).unsqueeze(0).expand(B, -1)
+        past1 = models.BranchPast(text=text, ancestors=[[] for _ in range(L)], ctx_len=ctx_len, paths=[[0]], n_query_nodes=1)
+        o1 = model(input_ids=b_ids, position_ids=pos1, textualPast=past1, use_cache=True, returnLmLogits=lm_head)
+        past2 = models.BranchPast(text=text, ancestors=[[o1.past_key_values[l]] for l in range(L)], ctx_len=ctx_len, paths=[[0, 1]],
+                                  n_query_nodes=1)
+        o2 = model(input_ids=b_ids.flip(1), position_ids=pos1 + 1, textualPast=past2, use_cache=True, returnLmLogits=lm_head)
+        # one-pass tree: node 0 and node 1 at depth 1, node 2 a child of node 0
+        depths = torch.tensor([1, 1, 2], device="cuda")
+        pos3 = (sparse.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, 3 * K).expand(B, -1).to(torch.int32)
+        past3 = models.BranchPast(text=text, ancestors=[[] for _ in range(L)], ctx_len=ctx_len, paths=[[0], [1], [0, 2]], n_query_nodes=3)
+        o3 = model(input_ids=t_ids, position_ids=pos3, textualPast=past3, use_cache=True, returnLmLogits=lm_head)
+        outs = [out.logits, o1.logits, o2.logits, o3.logits]
+        loss = sum((o.float() ** 2).mean() * (i + 1) for i, o in enumerate(outs)) + o3.last_hidden_state.float().sum() * 1e-3
+        loss.backward()
+        return [o.detach().clone() for o in outs], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        ref_out, ref_grad = run(False)
+        got_out, got_grad = run(True)
+    finally:
+        fused.ENABLED = True
+    for a, b in zip(got_out, ref_out):
+        assert torch.allclose(a, b, atol=5e-5, rtol=1e-4)
+    assert set(got_grad) == set(ref_grad)
+    for n in ref_grad:
+        assert torch.allclose(got_grad[n], ref_grad[n], atol=5e-5, rtol=2e-3), n
+
+
+def test_fused_gpt2_bf16_autocast_close_to_modules():
+    from branchgan import fused
+    model = _gpt2(hidden=128, heads=2)
+    ids = torch.randint(0, 97, (4, 32), device="cuda")
+
+    def run(enabled):
+        fused.ENABLED = enabled
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(input_ids=ids, returnLmLogits=True)
+        F.cross_entropy(out.logits.float().flatten(0, 1), ids.flatten()).backward()
+        return out.logits.float().detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        ref_out, ref_grad = run(False)
+        got_out, got_grad = run(True)
+    finally:
+        fused.ENABLED = True
+    assert got_out.dtype == torch.float32 and torch.allclose(got_out, ref_out, atol=3e-2, rtol=3e-2)
+    for n in ref_grad:      # two bf16 computations of the same gradient: compare by relative Frobenius error
+        err = (got_grad[n] - ref_grad[n]).norm() / (ref_grad[n].norm() + 1e-12)
+        assert err < 5e-2, (n, float(err))
