@@ -98,10 +98,12 @@ _ws = {}
 
 
 def _workspace(nbytes, device):
-    ws = _ws.get(device)
+    """Grow-only scratch per (device, stream): kernels of two streams may run at the same time."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 4 << 20), dtype=torch.uint8, device=device)
-        _ws[device] = ws
+        _ws[key] = ws
     return ws
 
 

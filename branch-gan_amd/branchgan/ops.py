@@ -11,6 +11,7 @@ import torch
 from . import _capi as C
 
 _ws_cache = {}
+MAX_SLOTS = 64        # BG_MAX_SLOTS of include/branchgan.h: tree nodes one attention call can address
 
 # Optional per-kernel timing with HIP events on the launch stream (bench.py turns it on): name -> [(start, end), ...]
 TIMING = None
@@ -39,13 +40,14 @@ def timing_summary():
 
 
 def _workspace(nbytes, device):
-    """Grow-only per-device scratch for kernels that need one (top-n partials)."""
+    """Grow-only scratch per (device, stream) for kernels that need one (top-n partials)."""
     if nbytes == 0:
         return None
-    ws = _ws_cache.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[device] = ws
+        _ws_cache[key] = ws
     return ws
 
 

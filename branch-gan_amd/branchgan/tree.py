@@ -10,6 +10,8 @@ node fields callers read.  What changed underneath (all exactness-preserving, SU
   * the discriminator scores EVERY branch node in ONE forward (multiStepDiscForward walks node by node in the
     reference, :357-362): query (node, k) sees text[0..s_k], its ancestors' column k and itself.
 """
+import contextlib
+
 import torch
 
 from . import ops
@@ -211,6 +213,60 @@ def _clean(params):
     return {k: v for k, v in params.items() if k not in ('includeFinalTimeStep', 'blockSamplingOfLabels', 'dropoutRate')}
 
 
+def _branch_step(generator, node, device, dropoutRate, numAlterations, strat, params, noise_fn, ids=None):
+    """One generator forward over a branch node and the sampling of its children: -> (log probs (B,K,n), past, ids (B,n,K)).
+    With `ids` given nothing is sampled: the log probs of those ids are returned (re-forward with autograd)."""
+    predIDs, positionalIDs, past, _ = node.producePredictionStep(device)
+    output = generator.forward({'input_ids': predIDs, 'position_ids': positionalIDs, 'textualPast': past,
+                                'returnLmLogits': True, 'use_cache': True, 'dropoutRate': dropoutRate})
+    step_logits = output.prediction.logits                                                # (B, K, V)
+    B, K, V = step_logits.shape
+    if ids is None:
+        ids = _sample_rows(step_logits.detach().reshape(B * K, V), None, None, numAlterations, strat, params, B, K, noise_fn)
+    _, lp = ops.softmax_stats(step_logits, ids.permute(0, 2, 1).contiguous())            # (B, K, n)
+    return lp, output.prediction.past_key_values, ids
+
+
+def _set_child_log_probs(node, lp):
+    for j, child in enumerate(node.children):
+        child.logProbs = lp[:, :, j]
+        child.probs = child.logProbs.exp()
+
+
+def _attach_branch_gradients(generator, root, forwarded, device):
+    """Gives the children of every forwarded branch node autograd-connected log probs: one tree pass over all of them
+    (<= BG_MAX_SLOTS nodes), else node by node in depth order."""
+    B, K = forwarded[0].ids.shape
+    N = len(forwarded)
+    if N > ops.MAX_SLOTS:
+        for node in forwarded:
+            ids = torch.stack([c.ids for c in node.children], dim=1)
+            lp, past, _ = _branch_step(generator, node, device, None, ids.shape[1], None, None, None, ids=ids)
+            node.past = past
+            _set_child_log_probs(node, lp)
+        return
+    index = {id(n): i for i, n in enumerate(forwarded)}
+    paths = [[index[id(a)] for a in n.ancestors()] + [i] for i, n in enumerate(forwarded)]
+    sparseIndex = root.sparseIndex.to(device)
+    all_ids = torch.stack([n.ids.detach() for n in forwarded], dim=1).reshape(B, N * K).to(device)
+    depths = _depths_tensor(tuple(n.depth for n in forwarded), device)
+    pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
+    L = len(root.past)
+    past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
+                      ctx_len=ctx_len_of(sparseIndex, device), paths=paths, n_query_nodes=N)
+    out = generator.forward({'input_ids': all_ids, 'position_ids': pos, 'textualPast': past, 'returnLmLogits': True,
+                             'use_cache': False})
+    n_max = max(len(n.children) for n in forwarded)
+    gather = torch.full((B, N, K, n_max), -1, dtype=torch.int64, device=device)
+    for i, n in enumerate(forwarded):
+        for j, c in enumerate(n.children):
+            gather[:, i, :, j] = c.ids
+    _, lp = ops.softmax_stats(out.prediction.logits, gather.view(B, N * K, n_max))
+    lp = lp.view(B, N, K, n_max)
+    for i, n in enumerate(forwarded):
+        _set_child_log_probs(n, lp[:, i])
+
+
 def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=True, clearFullTree=False, verbose=False,
                         sparseIndex=None, noise_fn=None):
     """MultiStepPrediction.py:243-332.  Returns (root, firstPrediction, firstProbs (lazy), maskedProbs (lazy));
@@ -254,12 +310,15 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
     root.addGeneratorPredictionToNode(sparseAltIDs, firstOutput.prediction.past_key_values, None, altLogProbs.exp(),
                                       isRandomSamples=randomNodeInfo, logProbs=altLogProbs)
 
+    # Sampling is sequential by depth, differentiation is not: the branch forwards below run WITHOUT autograd (they only have
+    # to produce ids), then ONE pass over every forwarded node (the same tree attention the discriminator uses) rebuilds their
+    # logits with autograd, so the backward is one pass over N*K tokens instead of one per node.  Same mathematics as the
+    # reference's per-node graph (MultiStepPrediction.py:296-327); dropout would draw different masks, so it keeps the old way.
+    track = torch.is_grad_enabled() and logits.requires_grad
+    deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules)
+    forwarded = []
     for rule in sampleRules[1:]:
         for node in root.getLeaves(rule.continueFromRandom):
-            predIDs, positionalIDs, past, _ = node.producePredictionStep(device)
-            output = generator.forward({'input_ids': predIDs, 'position_ids': positionalIDs, 'textualPast': past,
-                                        'returnLmLogits': True, 'use_cache': True,
-                                        'dropoutRate': rule.samplingParams.get('dropoutRate', None)})
             if node.beam == 0 and rule.firstBeamSamplingStrategy is not None:
                 strat, params = rule.firstBeamSamplingStrategy, rule.firstBeamSamplingParams
                 numAlterations = rule.numAlterations + params['numRandomSamples']
@@ -267,20 +326,35 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
                 strat, params, numAlterations = rule.samplingStrategy, rule.samplingParams, rule.numAlterations
             params['includeFinalTimeStep'] = True
             params['blockSamplingOfLabels'] = False
-            step_logits = output.prediction.logits                                        # (B, K, V)
-            altIDs = _sample_rows(step_logits.detach().reshape(B * K, V), None, None, numAlterations, strat, params, B, K, noise_fn)
-            _, lp = ops.softmax_stats(step_logits, altIDs.permute(0, 2, 1).contiguous())  # (B, K, n)
-            node.addGeneratorPredictionToNode(altIDs, output.prediction.past_key_values, None, lp.exp(),
-                                              getRandomNodesFromRule(strat, params, numAlterations), logProbs=lp)
+            with torch.no_grad() if deferred else contextlib.nullcontext():
+                lp, past, altIDs = _branch_step(generator, node, device, rule.samplingParams.get('dropoutRate', None),
+                                                numAlterations, strat, params, noise_fn)
+            node.addGeneratorPredictionToNode(altIDs, past, None, lp.exp(), getRandomNodesFromRule(strat, params, numAlterations),
+                                              logProbs=lp)
+            forwarded.append(node)
+    if deferred and forwarded:
+        _attach_branch_gradients(generator, root, forwarded, device)
     if clearTreePast or clearFullTree:
         clearTree(root, clearFullTree)
     return root, firstOutput.prediction, firstOutput.classProbs, \
         SamplingStrategies.MaskedProbs(firstOutput.classProbs, inputIDs, True, True)
 
 
+def discRootForward(discriminator, ids, dualValueHeads=False):
+    """The discriminator's pass over the real text (MultiStepPrediction.py:340-347).  It does not depend on the generator,
+    so GannSetup runs it on a side stream while the generator builds the tree."""
+    out = discriminator.forward({'input_ids': ids, 'use_cache': True, 'output_hidden_states': False},
+                                doDiscForward=False, doTransformerPassWithPrediction=True)
+    inV = altV = None
+    if dualValueHeads:
+        _, inV, altV = discriminator.forward({'pred': out.transformerPred}, doDiscForward=False, doFinalizeSinglePrediction=True)
+    return out, inV, altV
+
+
 def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePast=True, clearFullTree=False,
-                         dualValueHeads=False):
-    """MultiStepPrediction.py:335-366, as TWO forwards: the root pass and one pass over every branch node."""
+                         dualValueHeads=False, rootPass=None):
+    """MultiStepPrediction.py:335-366, as TWO forwards: the root pass (optionally precomputed: `rootPass` = the result of
+    discRootForward on the same ids) and one pass over every branch node."""
     root = predictionTreeRoot
     nodes = root.getSubNodes()
     ids = root.ids.detach().to(device)
@@ -292,9 +366,7 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
             _, inV, altV = discriminator.forward({'pred': trans}, doDiscForward=False, doFinalizeSinglePrediction=True)
         return (inV, altV) if dualValueHeads else (None, None)
 
-    out = discriminator.forward({'input_ids': ids, 'use_cache': True, 'output_hidden_states': False},
-                                doDiscForward=False, doTransformerPassWithPrediction=True)
-    inV, altV = finish(root, out)
+    out, inV, altV = rootPass if rootPass is not None else discRootForward(discriminator, ids, dualValueHeads)
     root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction), out.transformerPred.past_key_values, None,
                                  {'InputValue': inV, 'AlterationsValue': altV} if dualValueHeads else None)
     if nodes:
