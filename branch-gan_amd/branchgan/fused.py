@@ -291,6 +291,85 @@ def linear(x, weight, bias, layout, dtype, act=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # attention on the packed QKV projection
 # ---------------------------------------------------------------------------------------------------------------------
+def _attn_fwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse):
+    path, path_len, max_path = ops.path_tables(paths, q5.device)
+    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+    with ops._timed("branch_attn_fwd"):
+        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
+                                           ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
+                                           C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+
+
+def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv):
+    path, path_len, max_path = ops.path_tables(paths, q5.device)
+    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+    sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
+    delta = torch.empty_like(lse)
+    with ops._timed("branch_attn_bwd"):
+        C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
+                                           ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
+                                           C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), ops._ptr_array(dsk),
+                                           ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+
+
+def _heads_first(t, NQ, K):
+    """(B, NQ*K, H, Dh) slice of a packed buffer -> (B, H, NQ, K, Dh) strided view."""
+    return t.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
+
+
+class _MergedTreeAttention(torch.autograd.Function):
+    """Root text and every tree node in ONE sequence: qkv (B, S + N*K, 3, H, Dh).  Rows [0, S) attend causally among
+    themselves; rows of node n, branch point k attend to text rows j < ctx_len[k] of THE SAME qkv, their ancestors' column k
+    and themselves.  Two kernel calls on slices of the packed buffer each way; everything else of the layer (GEMMs,
+    LayerNorms) sees one batch of S + N*K rows.  Returns (att (B, T, E), k view, v view)."""
+
+    @staticmethod
+    def forward(ctx, qkv, spec):
+        B, T, _, H, Dh = qkv.shape
+        S, N = spec["n_text"], spec["n_query_nodes"]
+        K = (T - S) // N
+        att = torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
+        lse_r = torch.empty((B, H, 1, S), dtype=torch.float32, device=qkv.device)
+        lse_t = torch.empty((B, H, N, K), dtype=torch.float32, device=qkv.device)
+        kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+        kt, vt = kview[:, :, :S], vview[:, :, :S]
+        _attn_fwd_call(_heads_first(qkv[:, :S, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, qkv.device), [[]], spec["scale"],
+                       _heads_first(att[:, :S], 1, S), lse_r)
+        own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
+        _attn_fwd_call(_heads_first(qkv[:, S:, 0], N, K), kt, vt, own(kview), own(vview), spec["ctx_len"], spec["paths"], spec["scale"],
+                       _heads_first(att[:, S:], N, K), lse_t)
+        ctx.save_for_backward(qkv, att, lse_r, lse_t, spec["ctx_len"])
+        ctx.meta = (S, N, K, spec["scale"], spec["paths"])
+        ctx.set_materialize_grads(False)
+        return att.view(B, T, H * Dh), kview, vview
+
+    @staticmethod
+    def backward(ctx, datt, dk_out, dv_out):
+        qkv, att, lse_r, lse_t, ctx_len = ctx.saved_tensors
+        S, N, K, scale, paths = ctx.meta
+        B, T, _, H, Dh = qkv.shape
+        dqkv, dtmp = torch.empty_like(qkv), torch.empty_like(qkv)    # dtmp: the tree rows' contribution to the text keys / values
+        if datt is None:
+            datt = torch.zeros((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
+        do = datt.reshape(B, T, H, Dh).to(qkv.dtype).contiguous()
+        kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+        dkview, dvview = dqkv[:, :, 1].permute(0, 2, 1, 3), dqkv[:, :, 2].permute(0, 2, 1, 3)
+        kt, vt = kview[:, :, :S], vview[:, :, :S]
+        _attn_bwd_call(_heads_first(qkv[:, :S, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, qkv.device), [[]], scale,
+                       _heads_first(att[:, :S], 1, S), lse_r, _heads_first(do[:, :S], 1, S), _heads_first(dqkv[:, :S, 0], 1, S),
+                       dkview[:, :, :S], dvview[:, :, :S], [], [])
+        own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
+        _attn_bwd_call(_heads_first(qkv[:, S:, 0], N, K), kt, vt, own(kview), own(vview), ctx_len, paths, scale,
+                       _heads_first(att[:, S:], N, K), lse_t, _heads_first(do[:, S:], N, K), _heads_first(dqkv[:, S:, 0], N, K),
+                       dtmp[:, :, 1].permute(0, 2, 1, 3)[:, :, :S], dtmp[:, :, 2].permute(0, 2, 1, 3)[:, :, :S], own(dkview), own(dvview))
+        dqkv[:, :S, 1:].add_(dtmp[:, :S, 1:])
+        if dk_out is not None:
+            dkview.add_(dk_out)
+        if dv_out is not None:
+            dvview.add_(dv_out)
+        return dqkv, None
+
+
 class _PackedAttention(torch.autograd.Function):
     """qkv (B, T, 3, H, Dh) contiguous, T = NQ * K.  lp = None: root causal pass.  Otherwise lp carries the text KV
     (k_text, v_text as inputs so that their gradients flow), ctx_len and paths; ancestors' (k, v) follow as inputs.
@@ -401,6 +480,10 @@ def packed_attention(qkv, lp, scale):
     """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views)."""
     if lp is None:
         att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale)})
+    elif getattr(lp, "merged_text", 0):
+        spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes,
+                "n_text": lp.merged_text}
+        att, k, v = _MergedTreeAttention.apply(qkv, spec)
     else:
         spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes}
         anc_k = [a[0] for a in lp.ancestors]

@@ -30,16 +30,17 @@ _IGNORED_BUFFERS = (".attention.bias", ".attention.self_bias", ".attention.maske
 class BranchPast:
     """KV context + arithmetic mask of one branch forward over NQ query nodes x K branch points."""
 
-    def __init__(self, text, ancestors, ctx_len, paths, n_query_nodes=1):
-        self.text = text                    # per layer (k_text, v_text)  (B,H,S,Dh)
+    def __init__(self, text, ancestors, ctx_len, paths, n_query_nodes=1, merged_text=0):
+        self.merged_text = merged_text      # > 0: the first merged_text input tokens ARE the text (one pass over text + tree)
+        self.text = text                    # per layer (k_text, v_text)  (B,H,S,Dh); None in merged form
         self.ancestors = ancestors          # per layer list of (k, v) slots (B,H,K,Dh), possibly empty
         self.ctx_len = ctx_len              # int32 (K,) on the device: sparseIndex + 1
         self.paths = paths                  # per query node: slot indices; i < n_anc -> ancestors[i], else own node i - n_anc
         self.n_query_nodes = n_query_nodes
 
     def layer(self, i):
-        return SimpleNamespace(text=self.text[i], ancestors=self.ancestors[i], ctx_len=self.ctx_len, paths=self.paths,
-                               n_query_nodes=self.n_query_nodes)
+        return SimpleNamespace(text=self.text[i] if self.text is not None else None, ancestors=self.ancestors[i],
+                               ctx_len=self.ctx_len, paths=self.paths, n_query_nodes=self.n_query_nodes, merged_text=self.merged_text)
 
 
 def descriptor_from_bool_mask(mask, K, C):
@@ -244,6 +245,10 @@ class _LMBase(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
+    def supportsMergedTree(self, input_ids):
+        """Can text and tree nodes go through ONE forward (BranchPast.merged_text)?  Only on the fused block path."""
+        return _fused_eligible(self, input_ids, None, None, False)
+
     def load_state_dict(self, state_dict, strict=True, assign=False):
         """Accepts reference checkpoints: drops their mask buffers (bias / self_bias / masked_bias)."""
         return super().load_state_dict(strip_reference_buffers(state_dict), strict=strict, assign=assign)
@@ -275,6 +280,8 @@ def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidd
     if not fused.ENABLED or not input_ids.is_cuda or output_hidden_states or customCasualMask is not None:
         return False
     if textualPast is not None and not isinstance(textualPast, BranchPast):
+        return False
+    if not hasattr(model, "_fused_family"):
         return False
     if dropoutRate or cfg.resid_pdrop or cfg.embd_pdrop or cfg.attn_pdrop:
         return False
@@ -445,6 +452,7 @@ class NonResidualGPT2Model(_LMBase):
 
 class NonResidualGPT2LMHeadModel(_LMBase):
     """NonResidualDiscriminatorBase.py:383-511."""
+    _fused_family = "gpt2"
 
     def __init__(self, config):
         super().__init__()

@@ -341,8 +341,7 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
 
 
 def discRootForward(discriminator, ids, dualValueHeads=False):
-    """The discriminator's pass over the real text (MultiStepPrediction.py:340-347).  It does not depend on the generator,
-    so GannSetup runs it on a side stream while the generator builds the tree."""
+    """The discriminator's pass over the real text (MultiStepPrediction.py:340-347)."""
     out = discriminator.forward({'input_ids': ids, 'use_cache': True, 'output_hidden_states': False},
                                 doDiscForward=False, doTransformerPassWithPrediction=True)
     inV = altV = None
@@ -353,8 +352,8 @@ def discRootForward(discriminator, ids, dualValueHeads=False):
 
 def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePast=True, clearFullTree=False,
                          dualValueHeads=False, rootPass=None):
-    """MultiStepPrediction.py:335-366, as TWO forwards: the root pass (optionally precomputed: `rootPass` = the result of
-    discRootForward on the same ids) and one pass over every branch node."""
+    """MultiStepPrediction.py:335-366.  On the fused block path ONE forward over text + every branch node; otherwise TWO: the
+    root pass (optionally precomputed: `rootPass` = the result of discRootForward on the same ids) and one pass over the nodes."""
     root = predictionTreeRoot
     nodes = root.getSubNodes()
     ids = root.ids.detach().to(device)
@@ -366,9 +365,7 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
             _, inV, altV = discriminator.forward({'pred': trans}, doDiscForward=False, doFinalizeSinglePrediction=True)
         return (inV, altV) if dualValueHeads else (None, None)
 
-    out, inV, altV = rootPass if rootPass is not None else discRootForward(discriminator, ids, dualValueHeads)
-    root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction), out.transformerPred.past_key_values, None,
-                                 {'InputValue': inV, 'AlterationsValue': altV} if dualValueHeads else None)
+    tree_args = None
     if nodes:
         sparseIndex = root.sparseIndex.to(device)
         K, N = sparseIndex.numel(), len(nodes)
@@ -377,18 +374,43 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
         all_ids = torch.stack([n.ids.detach() for n in nodes], dim=1).reshape(B, N * K).to(device)
         depths = _depths_tensor(tuple(n.depth for n in nodes), device)
         pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
-        L = len(root.past)
-        past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
-                          ctx_len=ctx_len_of(sparseIndex, device), paths=paths, n_query_nodes=N)
-        out = discriminator.forward({'input_ids': all_ids, 'position_ids': pos, 'textualPast': past, 'use_cache': True},
-                                    doDiscForward=False, doTransformerPassWithPrediction=True)
-        inV, altV = finish(None, out)
-        pred = out.prediction.view(B, N, K)
-        kv = out.transformerPred.past_key_values
+        tree_args = (K, N, paths, all_ids, pos, ctx_len_of(sparseIndex, device))
+
+    def node_outputs(pred, inV, altV, kv, K, N):
         for i, n in enumerate(nodes):
             vh = {'InputValue': inV.view(B, N, K, 1)[:, i], 'AlterationsValue': altV.view(B, N, K, 1)[:, i]} if dualValueHeads else None
             node_kv = [(k.unflatten(2, (N, K))[:, :, i], v.unflatten(2, (N, K))[:, :, i]) for k, v in kv]
             n.addDiscPredictionToNode(DiscriminatorOutput(pred[:, i]), node_kv, None, vh)
+
+    lm = getattr(discriminator, 'nonResidualModel', None)
+    if tree_args is not None and rootPass is None and lm is not None and lm.supportsMergedTree(ids) and \
+            tree_args[1] <= ops.MAX_SLOTS:
+        # ONE forward over [text | all tree nodes] (BranchPast.merged_text): every GEMM / LayerNorm of a layer sees one batch
+        K, N, paths, all_ids, pos, ctx_len = tree_args
+        L = lm.config.num_hidden_layers
+        pos_all = torch.cat((torch.arange(S, dtype=torch.int32, device=device).unsqueeze(0).expand(B, -1), pos), dim=1)
+        past = BranchPast(text=None, ancestors=[[] for _ in range(L)], ctx_len=ctx_len, paths=paths, n_query_nodes=N, merged_text=S)
+        out = discriminator.forward({'input_ids': torch.cat((ids, all_ids), dim=1), 'position_ids': pos_all, 'textualPast': past,
+                                     'use_cache': True}, doDiscForward=False, doTransformerPassWithPrediction=True)
+        inV, altV = finish(None, out)
+        kv = out.transformerPred.past_key_values
+        root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction[:, :S]), [(k[:, :, :S], v[:, :, :S]) for k, v in kv], None,
+                                     {'InputValue': inV[:, :S], 'AlterationsValue': altV[:, :S]} if dualValueHeads else None)
+        node_outputs(out.prediction[:, S:].reshape(B, N, K), inV[:, S:] if dualValueHeads else None,
+                     altV[:, S:] if dualValueHeads else None, [(k[:, :, S:], v[:, :, S:]) for k, v in kv], K, N)
+    else:
+        out, inV, altV = rootPass if rootPass is not None else discRootForward(discriminator, ids, dualValueHeads)
+        root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction), out.transformerPred.past_key_values, None,
+                                     {'InputValue': inV, 'AlterationsValue': altV} if dualValueHeads else None)
+        if tree_args is not None:
+            K, N, paths, all_ids, pos, ctx_len = tree_args
+            L = len(root.past)
+            past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
+                              ctx_len=ctx_len, paths=paths, n_query_nodes=N)
+            out = discriminator.forward({'input_ids': all_ids, 'position_ids': pos, 'textualPast': past, 'use_cache': True},
+                                        doDiscForward=False, doTransformerPassWithPrediction=True)
+            inV, altV = finish(None, out)
+            node_outputs(out.prediction.view(B, N, K), inV, altV, out.transformerPred.past_key_values, K, N)
     if clearTreePast or clearFullTree:
         clearTree(root, clearFullTree, clearAttMask=True, clearSparseIndex=True)
     return root
