@@ -31,6 +31,35 @@ def timeit(fn, iters=10, warmup=3):
     return s.elapsed_time(e) / iters
 
 
+def timeit_graphed(make_fn, reps=20, iters=10):
+    """Kernels of a few microseconds: capture `reps` back-to-back calls in a HIP graph and time replays, so that the host's
+    launch cost (tens of microseconds through Python + ctypes) is not what is measured.  `make_fn()` runs on the capture
+    stream and returns the callable to time (autograd runs a backward node on its forward's stream, so the forward that a
+    timed backward belongs to has to be made there too)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn = make_fn()
+        for _ in range(3):
+            fn()
+    side.synchronize()
+    timing, ops.TIMING = ops.TIMING, None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(reps):
+            fn()
+    ops.TIMING = timing
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (iters * reps)
+
+
 def report(name, ms, nbytes=None, flops=None, **kw):
     out = {"case": name, "ms": round(ms, 4)}
     if nbytes:
@@ -42,6 +71,8 @@ def report(name, ms, nbytes=None, flops=None, **kw):
 
 
 def sampling(rows, V):
+    small = rows <= 1024
+    timeit = (lambda f, **kw: timeit_graphed(lambda: f)) if small else globals()['timeit']
     g = torch.Generator(device="cuda").manual_seed(2)
     logits = 3.0 * torch.randn(rows, V, device="cuda", generator=g)
     probs = torch.softmax(logits, -1)
@@ -58,20 +89,22 @@ def sampling(rows, V):
         ms = timeit(lambda: ops.topn_select(probs, n, noise=noise, blocked=blocked))
         report(f"SAMPLE_NO_REPLACEMENT n={n} rows={rows} V={V}", ms, 2 * rows * V * e + rows * n * 12)
     for p in (0.5, 0.9):
-        ms = timeit(lambda: ops.topp_select(probs, 4, noise, p, blocked=blocked), iters=5)
+        ms = timeit(lambda: ops.topp_select(probs, 4, noise, p, blocked=blocked))
         report(f"TOP_P p={p} n=4 rows={rows} V={V}", ms, 2 * rows * V * e + rows * 4 * 12)
     ids = torch.randint(0, V, (rows, 2), device="cuda", generator=g)
     for dt, es in ((torch.float32, 4), (torch.bfloat16, 2)):
         x = logits.to(dt).requires_grad_(True)
         ms = timeit(lambda: ops.softmax_stats(x.detach(), ids))
         report(f"softmax_stats_fwd rows={rows} V={V} {dt}", ms, rows * V * es)
-        lse, lp = ops.softmax_stats(x, ids)
-        gl, gp = torch.randn_like(lse), torch.randn_like(lp)
-        ms = timeit(lambda: torch.autograd.grad((lse, lp), x, (gl, gp), retain_graph=True))
+        def make_bwd(x=x):
+            lse, lp = ops.softmax_stats(x, ids)
+            gl, gp = torch.randn_like(lse), torch.randn_like(lp)
+            return lambda: torch.autograd.grad((lse, lp), x, (gl, gp), retain_graph=True)
+        ms = timeit_graphed(make_bwd) if small else globals()['timeit'](make_bwd())
         report(f"softmax_stats_bwd rows={rows} V={V} {dt}", ms, 2 * rows * V * es)
     # reference op chain on the same GPU for scale (torch.argsort over V = what _topKSampling does)
     sub = probs[:1024]
-    ms = timeit(lambda: torch.argsort(sub, dim=-1, descending=True)[:, :4], iters=3, warmup=1)
+    ms = globals()['timeit'](lambda: torch.argsort(sub, dim=-1, descending=True)[:, :4], iters=3, warmup=1)
     report(f"[torch] argsort-based top-k rows=1024 V={V} (scaled x{rows // 1024} for {rows} rows)", ms * rows / 1024, rows * V * e)
 
 
@@ -92,20 +125,24 @@ def attention(B, H, Dh, S, K, depth, dtype):
         flops = 4 * Dh * H * B * pairs
         nbytes = (2 * B * H * Dh * (int(ctx.max()) + n_slots * K) + 2 * B * H * NQ * K * Dh) * e
         f = lambda: ops.branch_attention(q, kt, vt, ctx, ks, vs, paths=paths)[0]
-        ms = timeit(lambda: f())
+        ms = timeit_graphed(lambda: f)
         report(f"branch_attn fwd {label} B{B} H{H} Dh{Dh} S{S} K{K} d{depth} {dtype}", ms, nbytes, flops, mfma_frac=round(flops / ms / 1e9 / (MFMA_BF16 if e == 2 else MFMA_F32), 4))
-        out = f()
-        go = torch.randn_like(out)
-        ms = timeit(lambda: torch.autograd.grad(out, [q, kt, vt] + ks + vs, go, retain_graph=True))
+        def make_bwd():
+            out = f()
+            go = torch.randn_like(out)
+            return lambda: torch.autograd.grad(out, [q, kt, vt] + ks + vs, go, retain_graph=True)
+        ms = timeit_graphed(make_bwd)
         report(f"branch_attn bwd {label} B{B} H{H} Dh{Dh} S{S} K{K} d{depth} {dtype}", ms, 2.5 * nbytes, 2.5 * flops)
     # root causal pass
     q, k, v = mk(B, H, S, Dh), mk(B, H, S, Dh), mk(B, H, S, Dh)
     flops = 4 * Dh * H * B * S * (S + 1) // 2
-    ms = timeit(lambda: ops.causal_attention(q, k, v)[0])
+    ms = timeit_graphed(lambda: (lambda: ops.causal_attention(q, k, v)[0]))
     report(f"causal_attn fwd B{B} H{H} Dh{Dh} S{S} {dtype}", ms, 4 * B * H * S * Dh * e, flops, mfma_frac=round(flops / ms / 1e9 / (MFMA_BF16 if e == 2 else MFMA_F32), 4))
-    out = ops.causal_attention(q, k, v)[0]
-    go = torch.randn_like(out)
-    ms = timeit(lambda: torch.autograd.grad(out, [q, k, v], go, retain_graph=True))
+    def make_cbwd():
+        out = ops.causal_attention(q, k, v)[0]
+        go = torch.randn_like(out)
+        return lambda: torch.autograd.grad(out, [q, k, v], go, retain_graph=True)
+    ms = timeit_graphed(make_cbwd)
     report(f"causal_attn bwd B{B} H{H} Dh{Dh} S{S} {dtype}", ms, 10 * B * H * S * Dh * e, 2.5 * flops)
 
 

@@ -68,19 +68,48 @@ def compute_dtype(ref):
     return ref.dtype
 
 
+def _cache_key(p):
+    return (p._version, p.data_ptr(), _step_epoch, torch.cuda.is_current_stream_capturing(), _capture_epoch)
+
+
 def lowp(p, dtype):
     """The parameter in the compute dtype; one cast per parameter version (optimizer step), shared by every tree node's
-    forward and backward of that step."""
+    forward and backward of that step.  `prepare_weights` refreshes a whole model's copies with one multi-tensor launch."""
     if p.dtype == dtype:
         return p.detach()
-    capturing = torch.cuda.is_current_stream_capturing()
     hit = _cast_cache.get(id(p))
-    if hit is not None and hit[0] is p and hit[1] == (p._version, p.data_ptr(), _step_epoch) and hit[2].dtype == dtype and \
-            hit[3] == capturing and (not capturing or hit[4] == _capture_epoch):
+    if hit is not None and hit[0] is p and hit[1] == _cache_key(p) and hit[2].dtype == dtype:
         return hit[2]
-    t = p.detach().to(dtype)
-    _cast_cache[id(p)] = (p, (p._version, p.data_ptr(), _step_epoch), t, capturing, _capture_epoch)
+    capturing = torch.cuda.is_current_stream_capturing()
+    reuse = hit is not None and hit[0] is p and hit[2].dtype == dtype and hit[3] == (capturing, _capture_epoch if capturing else 0)
+    t = hit[2] if reuse else torch.empty_like(p, dtype=dtype)      # same memory pool (eager / this capture): overwrite in place
+    t.copy_(p.detach())
+    _cast_cache[id(p)] = (p, _cache_key(p), t, (capturing, _capture_epoch if capturing else 0))
     return t
+
+
+def prepare_weights(module, dtype):
+    """Refreshes the low-precision copies of every stale >= 2-D parameter (and bias) of `module` in one multi-tensor copy
+    instead of one cast kernel per parameter.  Called at the top of a fused model forward; cheap when nothing is stale."""
+    if dtype == torch.float32:
+        return
+    capturing = torch.cuda.is_current_stream_capturing()
+    pool = (capturing, _capture_epoch if capturing else 0)
+    src, dst = [], []
+    for p in module.parameters():
+        if p.dtype != torch.float32:
+            continue
+        hit = _cast_cache.get(id(p))
+        key = _cache_key(p)
+        if hit is not None and hit[0] is p and hit[1] == key and hit[2].dtype == dtype:
+            continue
+        reuse = hit is not None and hit[0] is p and hit[2].dtype == dtype and hit[3] == pool
+        t = hit[2] if reuse else torch.empty_like(p, dtype=dtype)
+        _cast_cache[id(p)] = (p, key, t, pool)
+        src.append(p.detach())
+        dst.append(t)
+    if src:
+        torch._foreach_copy_(dst, src)
 
 
 def _grad_buffer(p):

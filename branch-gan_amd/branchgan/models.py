@@ -477,6 +477,7 @@ class NonResidualGPT2LMHeadModel(_LMBase):
         tr = self.transformer
         if _fused_eligible(self, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate):
             dtype = fused.compute_dtype(tr.wte.weight)
+            fused.prepare_weights(self, dtype)
             with torch.autocast("cuda", enabled=False):
                 x, delta, presents = tr.wte(input_ids) + tr.wpe(pos.long()), None, []
                 for i, block in enumerate(tr.h):

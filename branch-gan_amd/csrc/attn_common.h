@@ -11,6 +11,8 @@
 // register r is one k-step whose half h is row (r&3) + 8(r>>2) + 4h.  The other operand is gathered
 // from LDS in exactly that row order.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace bg {
@@ -105,6 +107,47 @@ __device__ __forceinline__ void stage_tile(const T* g, int64_t rs, int row0, int
     }
   }
 }
+
+// The same staging split in two, so that the global loads of tile i+1 are in flight while tile i is consumed:
+// tile_load fills per-thread registers, tile_store writes them to LDS (row and / or transposed layout).
+template <typename T, int DH, int NTHREADS> struct TileRegs {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int CHUNKS = ATT_TILE * DH / VEC;
+  static constexpr int PER = (CHUNKS + NTHREADS - 1) / NTHREADS;
+  typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x8>::type V;
+  V v[PER];
+  __device__ __forceinline__ void load(const T* g, int64_t rs, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NTHREADS;
+      const int r = c / (DH / VEC), d0 = (c % (DH / VEC)) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = (T)0.0f;
+      if (c < CHUNKS && row0 + r < nrows) v[i] = *(const V*)(g + (int64_t)(row0 + r) * rs + d0);
+    }
+  }
+  template <bool ROW, bool COL>
+  __device__ __forceinline__ void store(T* lds_row, T* lds_col, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NTHREADS;
+      if (c >= CHUNKS) continue;
+      const int r = c / (DH / VEC), d0 = (c % (DH / VEC)) * VEC;
+      if constexpr (sizeof(T) == 4) {
+        if constexpr (ROW) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lds_row[r * Lds<T, DH>::RSTRIDE + d0 + j] = v[i][j];
+        }
+      } else {
+        if constexpr (ROW) *(bf16x8*)(lds_row + r * Lds<T, DH>::RSTRIDE + d0) = v[i];
+        if constexpr (COL) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) lds_col[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = v[i][j];
+        }
+      }
+    }
+  }
+};
 
 // acc[32 x 32] += X_tile(rows r, reduce over d) * Y^T  where X comes from LDS "row" layout (A operand,
 // tile row on the lane) and Y's fragment for this lane's column is supplied by `yfrag(t)`.

@@ -57,12 +57,22 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
+  // software pipeline: the global loads of tile i+1 are issued before tile i is consumed
+  TileRegs<T, DH, 256> kreg, vreg;
+  if (block_ctx > 0) {
+    kreg.load(kt, sh.t_ss, 0, sh.S_text, tid);
+    vreg.load(vt, sh.t_ss, 0, sh.S_text, tid);
+  }
   for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
     __syncthreads();  // previous tile fully consumed
-    stage_tile<T, DH, true, false>(kt, sh.t_ss, kb, sh.S_text, k_row, nullptr, tid, 256);
-    if constexpr (sizeof(T) == 4) stage_tile<T, DH, true, false>(vt, sh.t_ss, kb, sh.S_text, v_z, nullptr, tid, 256);
-    else stage_tile<T, DH, false, true>(vt, sh.t_ss, kb, sh.S_text, nullptr, v_z, tid, 256);
+    kreg.template store<true, false>(k_row, nullptr, tid);
+    if constexpr (sizeof(T) == 4) vreg.template store<true, false>(v_z, nullptr, tid);
+    else vreg.template store<false, true>(nullptr, v_z, tid);
     __syncthreads();
+    if (kb + ATT_TILE < block_ctx) {
+      kreg.load(kt, sh.t_ss, kb + ATT_TILE, sh.S_text, tid);
+      vreg.load(vt, sh.t_ss, kb + ATT_TILE, sh.S_text, tid);
+    }
     if (kb >= wave_ctx) continue;  // wave-uniform
 
     f32x16 s;

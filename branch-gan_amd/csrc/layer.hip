@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(BiasActArgs a) {
   }
 }
 
-static int ln_groups(int64_t rows) {       // one row per wave up to 128 workgroups, then several rows per wave
+static int ln_groups(int64_t rows) {       // one row per wave up to 512 workgroups, then several rows per wave
   int64_t g = cdiv(rows, 4);
-  return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+  return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
 }
 static int bias_groups(int64_t rows) {
   int64_t g = cdiv(rows, 8);
