@@ -55,6 +55,89 @@ def build(workload, device, seed=0):
     return model, conf, rl, g_opt, d_opt
 
 
+def attention_forward_roofline(wl, device, dtype, reps=5):
+    """Roofline of the dominant hand-written kernel, branch_attn_fwd_kernel (the largest share of GPU time among this
+    library's kernels in a step, see profiles/).  One train step launches it with three shape classes per layer - root
+    causal pass, generator branch step at depth d (ancestor slots), tree pass over N nodes (generator gradient pass,
+    discriminator) - so the replay below issues EXACTLY one step's mix (same counts, shapes, strides, dtype: slices of a
+    packed QKV buffer like the fused block path) captured in a HIP graph, and times `reps` replays with HIP events on the
+    stream they are launched on.  Algorithmic bytes / FLOPs per launch follow SURVEY.md §8(d):
+      bytes = visible K/V read once (max ctx_len text rows + every slot's K rows) + Q read + O write;
+      flops = 4 * Dh * (visible query-key pairs)."""
+    from branchgan import configs, fused, ops
+    S, K, D, B = wl["S"], wl["K"], wl["D"], wl["B"]
+    e = 2 if dtype == torch.bfloat16 else 4
+    sparse = np.sort(np.random.RandomState(1234).choice(S - 1, K, replace=False))
+    ctx = torch.tensor(sparse + 1, dtype=torch.int32, device=device)
+    ctx_sum, ctx_max = int(ctx.sum()), int(ctx.max())
+    calls, tot_bytes, tot_flops = [], 0.0, 0.0
+
+    def packed(T, H, Dh):
+        return torch.randn(B, T, 3, H, Dh, device=device).to(dtype)
+
+    def add(fn, nbytes, flops, count):
+        nonlocal tot_bytes, tot_flops
+        calls.extend([fn] * count)
+        tot_bytes += nbytes * count
+        tot_flops += flops * count
+
+    for name, has_branch_steps, n_tree in ((wl["gen"], True, D - 1), (wl["disc"], False, D)):
+        cfg = configs.LMConfig.from_any(name)
+        H, Dh, L = cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
+        scale = 1.0 / Dh ** 0.5
+        root = packed(S, H, Dh)
+        att_r = torch.empty(B, S, H, Dh, device=device, dtype=dtype)
+        lse_r = torch.empty(B, H, 1, S, device=device)
+        kt, vt = root[:, :, 1].permute(0, 2, 1, 3), root[:, :, 2].permute(0, 2, 1, 3)
+        hf = fused._heads_first
+        add(lambda root=root, att_r=att_r, lse_r=lse_r, kt=kt, vt=vt, scale=scale:
+            fused._attn_fwd_call(hf(root[:, :, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, device), [[]], scale, hf(att_r, 1, S), lse_r),
+            4 * B * H * S * Dh * e, 4 * Dh * H * B * S * (S + 1) // 2, L)
+        steps = []
+        if has_branch_steps:                       # sampling passes: node at depth d sees d - 1 ancestor slots + itself
+            nodes = [packed(K, H, Dh) for _ in range(D - 1)]
+            for d in range(1, D):
+                steps.append((nodes[d - 1], [n[:, :, 1].permute(0, 2, 1, 3) for n in nodes[:d]], [n[:, :, 2].permute(0, 2, 1, 3) for n in nodes[:d]],
+                              [list(range(d))], 1))
+        tree = packed(n_tree * K, H, Dh)           # one pass over n_tree chain nodes
+        tk, tv = tree[:, :, 1].permute(0, 2, 1, 3), tree[:, :, 2].permute(0, 2, 1, 3)
+        steps.append((tree, [tk[:, :, n * K:(n + 1) * K] for n in range(n_tree)], [tv[:, :, n * K:(n + 1) * K] for n in range(n_tree)],
+                      [list(range(n + 1)) for n in range(n_tree)], n_tree))
+        for qkv, sk, sv, paths, NQ in steps:
+            att = torch.empty(B, NQ * K, H, Dh, device=device, dtype=dtype)
+            lse = torch.empty(B, H, NQ, K, device=device)
+            pairs = NQ * ctx_sum + K * sum(len(p) for p in paths)
+            add(lambda qkv=qkv, sk=sk, sv=sv, paths=paths, NQ=NQ, att=att, lse=lse, kt=kt, vt=vt, scale=scale:
+                fused._attn_fwd_call(hf(qkv[:, :, 0], NQ, K), kt, vt, sk, sv, ctx, paths, scale, hf(att, NQ, K), lse),
+                (2 * B * H * Dh * (ctx_max + len(sk) * K) + 2 * B * H * NQ * K * Dh) * e, 4 * Dh * H * B * pairs, L)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for fn in calls:
+            fn()
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for fn in calls:
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        graph.replay()
+    t1.record()
+    torch.cuda.synchronize()
+    n = len(calls)
+    avg_ms = t0.elapsed_time(t1) / (reps * n)
+    achieved = tot_bytes / n / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "branch_attn_fwd_kernel (bg_branch_attn_fwd): one step's launch mix (root causal / branch step / tree pass)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": tot_bytes / n, "avg_launch_ms": avg_ms, "launches_per_step": n,
+            "mfma": {"achieved_tflops": tot_flops / n / (avg_ms * 1e-3) / 1e12, "peak_tflops": 2500.0 if e == 2 else 157.3,
+                     "note": "arithmetic intensity 2*Q_vis/e flop/B is far below the ridge at these shapes: HBM is the binding roof (SURVEY.md §8d)"}}
+
+
 def cpu_baseline(workload, sample_batch, dtype_note):
     """The oracle (CPU restatement of the reference path, plain PyTorch fp32) on a bounded sample of the same workload:
     one step (forward of the whole GAN step + both backwards) at a reduced batch, timed on this host's cores."""
@@ -157,13 +240,7 @@ def main():
 
     ms = 1000.0 * elapsed / args.steps
     tokens = world * B * S * args.steps
-    # dominant hand-written kernel: the vocabulary backward of the root pass (read logits, write dlogits)
-    e = 2 if use_amp else 4
-    rows = B * S
-    name = f"softmax_stats_bwd[{rows}]"
-    n_launch, k_ms = kernels.get(name, (0, float("nan")))
-    algo_bytes = 2.0 * rows * V * e
-    achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if n_launch else float("nan")
+    roofline = attention_forward_roofline(wl, device, torch.bfloat16 if use_amp else torch.float32)
     out = {
         "metric": "branch-GAN train tokens/sec (gen+disc fwd/bwd)", "value": tokens / elapsed, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -171,11 +248,9 @@ def main():
         "config": {"workload": wl["name"], "per_gpu_batch": B, "seq_len": S, "branch_points": wl["K"], "depth": wl["D"],
                    "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay of fwd+bwd; all-reduce and Adam eager",
                    "precision": "bf16 autocast, fp32 master weights and accumulation" if use_amp else "fp32",
-                   "weights": "random init", "final_losses": {"gen": float(g["loss"]), "disc": float(d["loss"])}},
-        "roofline": {"bound": "hbm", "kernel": "softmax_stats_bwd_kernel (bg_softmax_stats_bwd, root pass)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": k_ms, "launches": n_launch},
-        "kernels_ms": {k: {"launches": v[0], "avg_ms": round(v[1], 4)} for k, v in sorted(kernels.items())},
+                   "weights": "random init", "final_losses": {"gen": float(g["loss"].detach()), "disc": float(d["loss"].detach())}},
+        "roofline": roofline,
+        "eager_event_ms": {k: {"launches": v[0], "avg_ms": round(v[1], 4)} for k, v in sorted(kernels.items())},   # includes host launch gaps
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_batch, args.dtype)
