@@ -140,6 +140,192 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
   if (valid && h == 0) a.lse[((int64_t)bh * sh.NQ + n) * sh.K + kq] = (l > 0.f) ? m + logf(l) : -INFINITY;
 }
 
+
+// ---- key-split variant (Dh <= 128) -------------------------------------------------------------------------------------
+// At Branch-GAN shapes a (batch, head) has only 32-256 query rows, so giving every wave its own 32 queries leaves most of
+// the chip idle behind one long dependent chain per wave (8 key tiles, one after the other).  Here a workgroup owns ONE
+// 32-query tile and its four waves split the KEY range: wave w takes text tiles w, w+4, ... and branch-path entries
+// w, w+4, ..., each with a private K/V staging area in LDS (no workgroup barrier inside the loop, next tile's global
+// loads in flight behind the current tile's MFMAs), and the four partial (max, sum, O) states are merged through LDS at
+// the end.  grid.x = number of 32-query tiles: 4x the workgroups and a 4x shorter chain per wave.
+template <typename T, int DH> struct SplitLds {
+  using L = Lds<T, DH>;
+  static constexpr int K_ELEMS = L::ROW_ELEMS;
+  static constexpr int V_ELEMS = sizeof(T) == 4 ? L::ROW_ELEMS : L::COL_ELEMS;
+  static constexpr size_t WAVE_BYTES = ((size_t)(K_ELEMS + V_ELEMS) * sizeof(T) + 15) / 16 * 16;
+  static constexpr size_t MERGE_BYTES = (size_t)ATT_WAVES * (DH + 2) * ATT_TILE * sizeof(float);
+  static constexpr size_t BYTES = (ATT_WAVES * WAVE_BYTES > MERGE_BYTES ? ATT_WAVES * WAVE_BYTES : MERGE_BYTES) + 64;
+};
+
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) {
+  using SL = SplitLds<T, DH>;
+  constexpr int NDT = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bg_attn_shape& sh = a.sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  T* k_row = (T*)(smem + wave * SL::WAVE_BYTES);
+  T* v_z = k_row + SL::K_ELEMS;
+  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int R = sh.NQ * sh.K;
+  const int rq = blockIdx.x * ATT_TILE + (lane & 31);
+  const bool valid = rq < R;
+  const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
+  int ctx = valid ? a.ctx_len[kq] : 0;
+  ctx = min(ctx, sh.S_text);
+
+  const T* q_row = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)kq * sh.q_sk;
+  const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  RowFrag<T, DH> qf;
+  qf.load(q_row, valid, h);
+
+  int tile_ctx = ctx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tile_ctx = max(tile_ctx, __shfl_xor(tile_ctx, o));
+  const int ntiles = (tile_ctx + ATT_TILE - 1) / ATT_TILE;
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+
+  TileRegs<T, DH, 64> kreg, vreg;
+  if (wave < ntiles) {
+    kreg.load(kt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
+    vreg.load(vt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
+  }
+  for (int t = wave; t < ntiles; t += ATT_WAVES) {
+    const int kb = t * ATT_TILE;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
+    kreg.template store<true, false>(k_row, nullptr, lane);
+    if constexpr (sizeof(T) == 4) vreg.template store<true, false>(v_z, nullptr, lane);
+    else vreg.template store<false, true>(nullptr, v_z, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave: stores land before the reads below
+    if (t + ATT_WAVES < ntiles) {
+      kreg.load(kt, sh.t_ss, kb + ATT_WAVES * ATT_TILE, sh.S_text, lane);
+      vreg.load(vt, sh.t_ss, kb + ATT_WAVES * ATT_TILE, sh.S_text, lane);
+    }
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    mma_reduce_d<T, DH>(s, k_row, lane, [&](int tt) { return qf.get(tt, h); });
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb + tile_row(r, h);
+      s[r] = (key < ctx) ? s[r] * sh.scale : -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m, tmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __expf(s[r] - m_use);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+  }
+
+  // branch keys, path entries wave, wave + 4, ...
+  const int plen = valid ? a.path_len[n] : 0;
+  for (int p = wave; p < sh.max_path; p += ATT_WAVES) {
+    const bool act = p < plen;
+    const int slot = act ? a.path[n * sh.max_path + p] : 0;
+    const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
+    const T* kr = nullptr;
+    const T* vr = nullptr;
+    for (int sidx = 0; sidx < sh.n_slots; ++sidx) {
+      if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
+    }
+    const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
+    if (act) {
+      const float m_new = fmaxf(m, sc);
+      const float alpha = __expf(m - m_new);
+      const float pw = __expf(sc - m_new);
+      l = l * alpha + pw;
+      m = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      axpy_rowvec<T, DH>(o, pw, vr, h, true);
+    }
+  }
+
+  // merge the four waves' states:  mo[wave][d][query], ml[wave][{m, l}][query]
+  __syncthreads();
+  float* mo = (float*)smem;
+  float* ml = mo + ATT_WAVES * DH * ATT_TILE;
+  const int qcol = lane & 31;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mo[(wave * DH + dt * 32 + tile_row(r, h)) * ATT_TILE + qcol] = o[dt][r];
+  if (h == 0) {
+    ml[(wave * 2 + 0) * ATT_TILE + qcol] = m;
+    ml[(wave * 2 + 1) * ATT_TILE + qcol] = l;
+  }
+  __syncthreads();
+  // thread -> query tid & 31, feature group tid >> 5 (8 groups of DH / 8 consecutive features)
+  {
+    constexpr int PER = DH / 8;
+    const int qi = tid & 31, grp = tid >> 5;
+    const int rq2 = blockIdx.x * ATT_TILE + qi;
+    if (rq2 < R) {
+      const int n2 = rq2 / sh.K, k2 = rq2 % sh.K;
+      float mw[ATT_WAVES], sw[ATT_WAVES], mstar = -INFINITY, lstar = 0.f;
+#pragma unroll
+      for (int w = 0; w < ATT_WAVES; ++w) {
+        mw[w] = ml[(w * 2 + 0) * ATT_TILE + qi];
+        mstar = fmaxf(mstar, mw[w]);
+      }
+#pragma unroll
+      for (int w = 0; w < ATT_WAVES; ++w) {
+        sw[w] = (mw[w] == -INFINITY) ? 0.f : __expf(mw[w] - mstar);
+        lstar += ml[(w * 2 + 1) * ATT_TILE + qi] * sw[w];
+      }
+      const float inv = (lstar > 0.f) ? 1.f / lstar : 0.f;
+      T* o_row = (T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n2 * sh.o_sn + (int64_t)k2 * sh.o_sk + grp * PER;
+      float acc[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_WAVES; ++w) v += mo[(w * DH + grp * PER + j) * ATT_TILE + qi] * sw[w];
+        acc[j] = v * inv;
+      }
+#pragma unroll
+      for (int j0 = 0; j0 < PER; j0 += 4) {
+        if constexpr (sizeof(T) == 4) {
+          f32x4 ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = acc[j0 + j];
+          *(f32x4*)(o_row + j0) = ov;
+        } else {
+          bf16x4 ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)acc[j0 + j];
+          *(bf16x4*)(o_row + j0) = ov;
+        }
+      }
+      if (grp == 0) a.lse[((int64_t)bh * sh.NQ + n2) * sh.K + k2] = (lstar > 0.f) ? mstar + logf(lstar) : -INFINITY;
+    }
+  }
+}
+
 size_t attn_fwd_lds_bytes(int dtype, int Dh) {
   if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
   return (size_t)(ATT_TILE * (Dh + 8) + Dh * (ATT_TILE + 4)) * 2 + 64;
@@ -165,11 +351,32 @@ int check_aligned16(const void* p, const char* who, const char* name) {
   return BG_OK;
 }
 
+template <typename T, int DH>
+static void launch_fwd_split(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = SplitLds<T, DH>::BYTES;
+  auto kernel = branch_attn_fwd_split_kernel<T, DH>;
+  set_lds_limit(kernel, lds);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+}
+
 template <typename T>
 static int launch_fwd(const AttnArgs& a, hipStream_t st) {
   const bg_attn_shape& sh = a.sh;
   dim3 grid((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H)), block(256);
   const size_t lds = attn_fwd_lds_bytes(sh.dtype, sh.Dh);
+  dim3 grid_split((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_TILE), (unsigned)(sh.B * sh.H));
+  // few query rows per (batch, head): split the keys over the waves (4x the workgroups, 4x shorter chains); many rows:
+  // the query-split kernel stages each K/V tile once for four waves (measured crossover at 128 rows, MI355X, Dh 64)
+  const int64_t R = (int64_t)sh.NQ * sh.K;
+  const bool split = sh.Dh <= 128 && R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512;
+  if (split) {
+    switch (sh.Dh) {
+      case 32: launch_fwd_split<T, 32>(a, grid_split, st); break;
+      case 64: launch_fwd_split<T, 64>(a, grid_split, st); break;
+      default: launch_fwd_split<T, 128>(a, grid_split, st); break;
+    }
+    return BG_OK;
+  }
   switch (sh.Dh) {
     case 32: hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 32>), grid, block, lds, st, a); break;
     case 64: hipLaunchKernelGGL((branch_attn_fwd_kernel<T, 64>), grid, block, lds, st, a); break;

@@ -99,13 +99,15 @@ def test_vs_oracle(B, H, Dh, S, K, depth, dtype):
     assert out.dtype == dtype and leaves["kt"].grad.dtype == dtype
 
 
-def test_multi_node_tree_one_pass_equals_node_by_node():
+@pytest.mark.parametrize("K", [7, 40])
+def test_multi_node_tree_one_pass_equals_node_by_node(K):
     """One launch over all nodes of a branching tree (paths differ per node) == per-node launches; gradients of shared
-    slots accumulate over the nodes that see them."""
+    slots accumulate over the nodes that see them.  K = 7: 35 query rows per head (key-split forward kernel);
+    K = 40: 200 rows (query-split kernel), while the per-node launches it is compared with take the other one."""
     from branchgan import ops
     gen = torch.Generator().manual_seed(3)
-    B, H, Dh, S, K = 2, 2, 64, 50, 7
-    sparse = torch.tensor([0, 3, 10, 11, 30, 40, 48])
+    B, H, Dh, S = 2, 2, 64, 50 if K == 7 else 130
+    sparse = torch.tensor([0, 3, 10, 11, 30, 40, 48]) if K == 7 else torch.from_numpy(np.sort(np.random.RandomState(5).choice(S - 1, K, replace=False)))
     ctx_len = (sparse + 1).int().cuda()
     paths = [[0], [0, 1], [2], [2, 3], [2, 4]]           # nodes: a, a1, b, b1, b2
     N = len(paths)
