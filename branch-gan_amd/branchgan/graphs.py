@@ -40,10 +40,16 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
+        # two graphs: [forward of everything + generator backward] and [discriminator backward].  Between them the
+        # generator's gradient all-reduce and Adam step start on a side stream and run behind the second graph.
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_d = torch.cuda.CUDAGraph()
         fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
         with torch.cuda.graph(self.graph):
-            self.losses = self._forward_backward()
+            self.losses = self._forward()
+            self.losses[1][self.g_opt.lossKey].backward()
+        with torch.cuda.graph(self.graph_d, pool=self.graph.pool()):
+            self.losses[0][self.d_opt.lossKey].backward()
         ops.TIMING = timing
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
         self.g_opt.arena.zero()
@@ -56,10 +62,13 @@ class GraphedTrainStep:
             sp = torch.arange(ids.shape[1], device=ids.device)
         self.static_sparse.copy_(sp.to(self.static_sparse.device), non_blocking=True)
 
-    def _forward_backward(self):
+    def _forward(self):
         with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
-            d, g = self.model.trainForwardPassNoMetrics(self.static_ids, self.conf, self.n_update, collectTreeDepthData=False,
+            return self.model.trainForwardPassNoMetrics(self.static_ids, self.conf, self.n_update, collectTreeDepthData=False,
                                                         reinforcementLearningConfig=self.rl, checkNaN=False)
+
+    def _forward_backward(self):
+        d, g = self._forward()
         g[self.g_opt.lossKey].backward()
         d[self.d_opt.lossKey].backward()
         return d, g
@@ -71,15 +80,24 @@ class GraphedTrainStep:
         for opt in (self.g_opt, self.d_opt):
             opt.finish(stepCounter % opt.gradAccum == 0)
 
+    def _start_update(self, opt, stepCounter, asynchronous):
+        stepped = stepCounter % opt.gradAccum == 0
+        if stepped:
+            opt.arena.reduce_async()
+        (opt.finish_async if asynchronous else opt.finish)(stepped)
+
     def step(self, inputIDs, stepCounter):
         """One train step: returns the (static) loss dicts; GanSetup.py:249-256's NaN guard is evaluated on the device and
         raised by check_nan() (one host sync when the caller chooses, not one per loss key per step)."""
         self.static_ids.copy_(inputIDs, non_blocking=True)
         self._refresh_sparse(inputIDs)
-        self.graph.replay()
+        self.graph.replay()                                # forward + generator backward
         d, g = self.losses
+        self._start_update(self.g_opt, stepCounter, asynchronous=True)
+        self.graph_d.replay()                              # discriminator backward, with G's all-reduce + Adam behind it
         self.nan_flag |= torch.isnan(g['loss'].detach())
-        self._finish(stepCounter)
+        self._start_update(self.d_opt, stepCounter, asynchronous=False)
+        self.g_opt.join()
         return d, g
 
     def check_nan(self):

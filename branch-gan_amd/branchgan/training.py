@@ -122,6 +122,27 @@ class OptimizerWrapper:
             if self.scheduler is not None:
                 self.scheduler.step()
 
+    def finish_async(self, stepped):
+        """`finish` on the arena's side stream: the all-reduce wait, the optimizer step and the zeroing of this model's
+        gradients run behind whatever the caller's stream does next (the OTHER model's backward).  `join()` before anything
+        on the caller's stream touches this model's parameters again.  Without a GPU it is plain `finish`."""
+        side = self.arena.stream
+        if side is None or not stepped:
+            return self.finish(stepped)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for w in self.arena._work:
+                w.wait()
+            self.arena._work = []
+            self.optimizer.step()
+            self.arena.zero()
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def join(self):
+        if self.arena.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.arena.stream)
+
     def performUpdateStep(self, losses, stepCounter):
         self.finish(self.backward(losses, stepCounter))
 
@@ -141,10 +162,11 @@ def train_step(model, inputIDs, sampleConf, generatorOptim, discriminatorOptim, 
     discriminator backward, gradient reduction, both optimizer steps."""
     discLosses, genLosses = model.trainForwardPassNoMetrics(inputIDs, sampleConf, numUpdateSamples, collectTreeDepthData=False,
                                                             reinforcementLearningConfig=reinforcementLearningConfig, **kwargs)
-    g_step = generatorOptim.backward(genLosses, stepCounter) if updateGen else False        # G's all-reduce overlaps D's backward
+    g_step = generatorOptim.backward(genLosses, stepCounter) if updateGen else False
+    generatorOptim.finish_async(g_step)          # G's all-reduce + Adam run on a side stream behind D's backward
     d_step = discriminatorOptim.backward(discLosses, stepCounter) if updateDisc else False
-    generatorOptim.finish(g_step)
     discriminatorOptim.finish(d_step)
+    generatorOptim.join()
     return discLosses, genLosses
 
 
