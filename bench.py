@@ -130,9 +130,15 @@ def attention_forward_roofline(wl, device, dtype, reps=5):
     torch.cuda.synchronize()
     n = len(calls)
     avg_ms = t0.elapsed_time(t1) / (reps * n)
+    # HBM traffic per launch from the PMC passes over this same launch mix (benchmarks/attn_mix.py under rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied): collected offline, a profiler cannot run in here
+    traffic, pmc = None, os.path.join(ROOT, "profiles", "r1_f_pmc_attn_fwd.json")
+    if wl.get("name") == WORKLOADS["c2"]["name"] and wl["B"] == WORKLOADS["c2"]["B"] and e == 2 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
     achieved = tot_bytes / n / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "branch_attn_fwd_kernel (bg_branch_attn_fwd): one step's launch mix (root causal / branch step / tree pass)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/r1_f_pmc_attn_fwd.json (rocprofv3 --pmc passes over benchmarks/attn_mix.py)" if traffic else None,
             "algorithmic_bytes_per_launch": tot_bytes / n, "avg_launch_ms": avg_ms, "launches_per_step": n,
             "mfma": {"achieved_tflops": tot_flops / n / (avg_ms * 1e-3) / 1e12, "peak_tflops": 2500.0 if e == 2 else 157.3,
                      "note": "arithmetic intensity 2*Q_vis/e flop/B is far below the ridge at these shapes: HBM is the binding roof (SURVEY.md §8d)"}}

@@ -27,9 +27,10 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
 
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const BlockXY blk = xcd_block();
+  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
-  const int rq = blockIdx.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
+  const int rq = blk.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
   const bool valid = rq < R;
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
   int ctx = valid ? a.ctx_len[kq] : 0;
@@ -128,9 +129,10 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
 
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const BlockXY blk = xcd_block();
+  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
-  const int key0_block = blockIdx.x * (ATT_WAVES * ATT_TILE);
+  const int key0_block = blk.x * (ATT_WAVES * ATT_TILE);
   const int key0_wave = key0_block + wave * ATT_TILE;
   const int key = key0_wave + (lane & 31);
   const bool kvalid = key < sh.S_text;

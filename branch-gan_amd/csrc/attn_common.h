@@ -47,6 +47,19 @@ static inline void set_lds_limit(K kernel, size_t lds) {
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  The kernels below index their work as
+// (tile = x, batch*head = y) with x fastest, so the tiles of one head - which read the SAME K/V - would land on different
+// XCDs and each L2 would fetch its own copy.  This remap gives every XCD a contiguous run of (head, tile) pairs instead.
+struct BlockXY {
+  int x, y;
+};
+__device__ __forceinline__ BlockXY xcd_block() {
+  const unsigned gx = gridDim.x, total = gx * gridDim.y;
+  unsigned lin = blockIdx.y * gx + blockIdx.x;
+  if (total % 8 == 0) lin = (lin % 8) * (total / 8) + lin / 8;
+  return BlockXY{(int)(lin % gx), (int)(lin / gx)};
+}
+
 __device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // LDS layouts ---------------------------------------------------------------------------------------

@@ -27,9 +27,10 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
 
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const BlockXY blk = xcd_block();
+  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
-  const int rq = blockIdx.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
+  const int rq = blk.x * (ATT_WAVES * ATT_TILE) + wave * ATT_TILE + (lane & 31);
   const bool valid = rq < R;
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
   int ctx = valid ? a.ctx_len[kq] : 0;
@@ -166,9 +167,10 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   T* k_row = (T*)(smem + wave * SL::WAVE_BYTES);
   T* v_z = k_row + SL::K_ELEMS;
-  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const BlockXY blk = xcd_block();
+  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
-  const int rq = blockIdx.x * ATT_TILE + (lane & 31);
+  const int rq = blk.x * ATT_TILE + (lane & 31);
   const bool valid = rq < R;
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
   int ctx = valid ? a.ctx_len[kq] : 0;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
   {
     constexpr int PER = DH / 8;
     const int qi = tid & 31, grp = tid >> 5;
-    const int rq2 = blockIdx.x * ATT_TILE + qi;
+    const int rq2 = blk.x * ATT_TILE + qi;
     if (rq2 < R) {
       const int n2 = rq2 / sh.K, k2 = rq2 % sh.K;
       float mw[ATT_WAVES], sw[ATT_WAVES], mstar = -INFINITY, lstar = 0.f;
