@@ -29,6 +29,7 @@ WORKLOADS = {
     "c3": dict(gen="pythia-410m", disc="pythia-14m", S=128, K=32, D=8, B=8,
                name="Pythia-410M G / Pythia-14m D PileTraining config, seq 128, 32 branches, depth 8, batch 8/GPU (BASELINE configs[2])"),
 }
+WORKLOADS["tiny"] = dict(gen="gpt2-tiny", disc="gpt2-tiny", S=64, K=8, D=3, B=4, name="rehearsal only: 2-layer 128-wide GPT-2 pair")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈6.3 TB/s achievable)
 
 
@@ -185,12 +186,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     args = ap.parse_args()
+    if os.environ.get("BRANCHGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BRANCHGAN_BENCH_WATCHDOG"]), exit=True)
 
     from branchgan import ops, training
     rank, world, local = training.init_data_parallel()
     if world != args.gpus and rank == 0:
         print(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; reporting n_gpus={world}", file=sys.stderr)
-    device = torch.device("cuda", local if world > 1 else 0)
+    device = torch.device("cuda", local % torch.cuda.device_count() if world > 1 else 0)
     torch.cuda.set_device(device)
     wl = dict(WORKLOADS[args.workload])
     if args.batch:

@@ -74,6 +74,7 @@ class LMConfig:
 # public model-card dims (SURVEY.md §8 header); dropout 0 as in every parity / benchmark run
 PRESETS = {
     "gpt2-small": LMConfig("gpt2", 50257, 768, 12, 12, 1024),
+    "gpt2-tiny": LMConfig("gpt2", 2048, 128, 2, 2, 256),          # not a published model: rehearsals of the multi-rank path
     "pythia-14m": LMConfig("gpt_neox", 50304, 128, 6, 4, 2048),
     "pythia-70m": LMConfig("gpt_neox", 50304, 512, 6, 8, 2048),
     "pythia-410m": LMConfig("gpt_neox", 50304, 1024, 24, 16, 2048),

@@ -8,11 +8,24 @@ The gradient all-reduce (RCCL) and the optimizer steps stay outside the graph, s
 The reference has no counterpart (it is eager PyTorch); results are identical to the eager step by construction.
 """
 import copy
+import os
 
 import torch
 
 from . import ops
 from . import fused
+
+
+def _sync_after_replay():
+    """Multi-rank runs wait on the host for a replayed graph before they issue the gradient all-reduce that depends on it.
+    Measured on MI355X / ROCm 7.2 with 2 ranks (gloo, one GPU): a collective enqueued while the graph it waits for is still
+    executing can deadlock (the collective's stream wait never fires; eager launches and finished graphs are fine).  The
+    all-reduce + Adam of the generator still overlap the discriminator's backward graph, which is launched right after; the
+    cost is one host round trip (~0.1 ms) per graph.  BRANCHGAN_GRAPH_SYNC=0/1 overrides."""
+    env = os.environ.get("BRANCHGAN_GRAPH_SYNC")
+    if env is not None:
+        return env == "1"
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
 class GraphedTrainStep:
@@ -29,6 +42,7 @@ class GraphedTrainStep:
         self.conf.sparseIndex = self.static_sparse
         self.graph = None
         self.losses = None
+        self._sync = _sync_after_replay()
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
         self._refresh_sparse(example_ids)
         side = torch.cuda.Stream(device=dev)
@@ -45,10 +59,10 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_d = torch.cuda.CUDAGraph()
         fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # collective backends run helper threads
             self.losses = self._forward()
             self.losses[1][self.g_opt.lossKey].backward()
-        with torch.cuda.graph(self.graph_d, pool=self.graph.pool()):
+        with torch.cuda.graph(self.graph_d, pool=self.graph.pool(), capture_error_mode="thread_local"):
             self.losses[0][self.d_opt.lossKey].backward()
         ops.TIMING = timing
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
@@ -92,9 +106,13 @@ class GraphedTrainStep:
         self.static_ids.copy_(inputIDs, non_blocking=True)
         self._refresh_sparse(inputIDs)
         self.graph.replay()                                # forward + generator backward
+        if self._sync:
+            torch.cuda.current_stream().synchronize()
         d, g = self.losses
         self._start_update(self.g_opt, stepCounter, asynchronous=True)
         self.graph_d.replay()                              # discriminator backward, with G's all-reduce + Adam behind it
+        if self._sync:
+            torch.cuda.current_stream().synchronize()
         self.nan_flag |= torch.isnan(g['loss'].detach())
         self._start_update(self.d_opt, stepCounter, asynchronous=False)
         self.g_opt.join()

@@ -30,7 +30,8 @@ def init_data_parallel(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "12345")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # BRANCHGAN_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU (RCCL refuses that)
+        backend = backend or os.environ.get("BRANCHGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
