@@ -35,6 +35,31 @@ __device__ __forceinline__ void wave_insert(u64& item, u64 c, int n, int lane) {
   if (lane >= n) item = 0;
 }
 
+// The wave's running state: sorted list (lane i = i-th best), tau = its n-th item (0 while the list is not full) and
+// tau_key = the float key of tau (NaN while not full, so that "key < tau_key" is false for every key).
+struct WaveList {
+  u64 item, tau;
+  float tau_key;
+  int n, lane;
+  __device__ __forceinline__ void init(int n_, int lane_) { item = 0; tau = 0; tau_key = order_bits_inv(0); n = n_; lane = lane_; }
+  __device__ __forceinline__ void offer(u64 c) {     // wave-uniform c
+    if (c > tau) {
+      wave_insert(item, c, n, lane);
+      tau = readlane64(item, n - 1);
+      tau_key = tau == 0 ? order_bits_inv(0) : order_bits_inv((uint32_t)(tau >> 32));
+    }
+  }
+  // every lane may bring one item (0 = none); offered in lane order
+  __device__ __forceinline__ void offer_lanes(u64 mine) {
+    u64 bal = __ballot(mine != 0);
+    while (bal) {
+      const int L = __ffsll((unsigned long long)bal) - 1;
+      bal &= bal - 1;
+      offer(readlane64(mine, L));
+    }
+  }
+};
+
 // Rank-merge `count` items held in LDS into the best n; each thread owns items t, t+blockDim, ...
 __device__ __forceinline__ void rank_merge_store(const u64* items, int count, int n, int64_t* out_ids, float* out_keys,
                                                  u64* out_partial) {

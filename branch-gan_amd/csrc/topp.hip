@@ -274,6 +274,360 @@ __global__ __launch_bounds__(256) void topp_kernel(ToppArgs a) {
   rank_merge_store(lds_items, 4 * n, n, a.out_ids + row * n, a.out_keys ? a.out_keys + row * n : nullptr, nullptr);
 }
 
+
+// ---- register-resident variant (V <= 53245) ------------------------------------------------------------------------------
+// The streaming kernel above re-reads the row once per radix level, the theta / cut passes and the final pass, and its
+// level-1 histogram serialises on the handful of buckets a softmax row falls into (LDS atomics, 50k elements on ~100
+// addresses).  Here 1024 threads hold the whole row in registers (13 x 16 B per thread), so HBM sees the row ONCE plus the
+// noise once; level 1 is the exponent alone (256 buckets) replicated 16 x by lane so that at most 4 lanes of a wave meet on
+// an address, levels 2 / 3 split the mantissa 12 + 11 bits, and a wave whose active lanes all hit ONE bucket (uniform and
+// near-uniform rows) adds once.  Same arithmetic as the streaming kernel: count + double sum per bucket, fp32 compare.
+#define TOPP_NV 13
+#define TOPP_THREADS 1024
+#define TOPP_CAP (TOPP_NV * TOPP_THREADS * 4)
+
+// Only the SUMS are histogrammed (one LDS atomic per positive element): a bucket matters to the scan iff its sum is positive -
+// zeros never move the prefix sum - and the multiplicity of the crossing value is counted from the registers afterwards.
+// scan_buckets for sum-only histograms: "non-empty" = positive sum.  Executed by wave 0; nb is a multiple of 64.
+__device__ void scan_sums(const double* sum, int nb, double cum0, float p32, Cross* out, int lane, bool force) {
+  const int per = nb / 64;
+  double s = 0.0;
+  for (int j = 0; j < per; ++j) s += sum[nb - 1 - (lane * per + j)];
+  double ps = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double os = shfl_up_d(ps, d);
+    if (lane >= d) ps += os;
+  }
+  double cum = cum0 + (ps - s);
+  int found = 0, fb = 0, lb = -1;
+  double fcum = 0.0, lcum = 0.0;
+  for (int j = 0; j < per && !found; ++j) {
+    const int b = nb - 1 - (lane * per + j);
+    if (!(sum[b] > 0.0)) continue;
+    lb = b; lcum = cum;
+    const double nxt = cum + sum[b];
+    if ((float)nxt > p32) { found = 1; fb = b; fcum = cum; }
+    else cum = nxt;
+  }
+  const unsigned long long bal = __ballot(found);
+  if (bal == 0) {
+    if (force) {
+      const unsigned long long ne = __ballot(lb >= 0);
+      const int last = 63 - __clzll(ne);
+      if (lane == last) { out->found = 1; out->bucket = lb; out->cnt_before = 0; out->cum_before = lcum; }
+    } else if (lane == 63) { out->found = 0; out->bucket = -1; out->cnt_before = 0; out->cum_before = cum; }
+  } else {
+    const int first = __ffsll(bal) - 1;
+    if (lane == first) { out->found = 1; out->bucket = fb; out->cnt_before = 0; out->cum_before = fcum; }
+  }
+}
+
+__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
+  __shared__ double h_sum[4096];
+  __shared__ double e_sum[256];
+  __shared__ u64 lds_items[(TOPP_THREADS / 64) * BG_MAX_TOPN];
+  __shared__ Cross cross;
+  __shared__ unsigned red_u[TOPP_THREADS / 64], red_v[TOPP_THREADS / 64];
+  __shared__ unsigned sh_theta, sh_ntheta;
+  __shared__ long long sh_idx_cut;
+  __shared__ float sh_mass;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const float* p = a.probs + row * a.stride;
+  const float* e = a.noise + row * a.noise_stride;
+  const int V = (int)a.V, n = a.n;
+  const float p32 = a.top_p;
+
+  uint32_t blk[BG_MAX_BLOCKED];
+#pragma unroll
+  for (int i = 0; i < BG_MAX_BLOCKED; ++i) {
+    int64_t b = (i < a.n_blocked) ? a.blocked[row * a.n_blocked + i] : -1;
+    blk[i] = (b >= 0 && b < a.V) ? (uint32_t)b : 0xFFFFFFFFu;
+  }
+  auto value = [&](int i) -> float {                  // global-memory view of element i (rare tie-at-the-cut pass only)
+    float v = p[i];
+    for (int b = 0; b < a.n_blocked; ++b)
+      if (blk[b] == (uint32_t)i) v = 0.f;
+    return v + 0.0f;
+  };
+
+  // ---- the row, once: vector c of thread t covers elements (c * 512 + t) * 4 - mis + {0..3}; outside [0, V): -1 (skipped) ----
+  const int mis = (int)((((uintptr_t)p) & 15) / 4);
+  float x[TOPP_NV][4];
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    if (i0 >= 0 && i0 + 4 <= V) {
+      const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p + i0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[c][j] = raw[j] + 0.0f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[c][j] = (i0 + j >= 0 && i0 + j < V) ? p[i0 + j] + 0.0f : -1.0f;
+    }
+    for (int b = 0; b < a.n_blocked; ++b) {
+      const uint32_t d = blk[b] - (uint32_t)i0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (d == (uint32_t)j && i0 + j >= 0) x[c][j] = 0.f;
+    }
+  }
+  auto clear_hist = [&](int nb) {
+    for (int i = tid; i < nb; i += TOPP_THREADS) h_sum[i] = 0.0;
+    __syncthreads();
+  };
+  auto present = [](unsigned u) { return (int)u >= 0; };          // sign bit = padding
+
+  // ---- level 1: exponent (bits 30:23), 16 lane-replicas per bucket -----------------------------------------------------
+  clear_hist(4096);
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = x[c][j];
+      if (v > 0.f) atomicAdd(&h_sum[((__float_as_uint(v) >> 23) & 255u) * 16 + (lane & 15)], (double)v);
+    }
+  __syncthreads();
+  if (tid < 256) {
+    double ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss += h_sum[tid * 16 + r];
+    e_sum[tid] = ss;
+  }
+  __syncthreads();
+  if (wave == 0) scan_sums(e_sum, 256, 0.0, p32, &cross, lane, false);
+  __syncthreads();
+  const bool crossing = cross.found != 0;
+  unsigned prefix = 0;
+  double cum_gt = cross.cum_before;
+  unsigned n_eq = 0;
+  if (crossing) {
+    const unsigned b1 = (unsigned)cross.bucket;
+    // All values of the crossing exponent identical (uniform rows, heavy ties)?  Then that value IS the crossing value and
+    // the two mantissa levels - whose atomics would all hit one address - are skipped.
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u = __float_as_uint(x[c][j]);
+        if (x[c][j] > 0.f && (u >> 23) == b1) { mn = min(mn, u); mx = max(mx, u); }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    }
+    if (lane == 0) { red_u[wave] = mn; red_v[wave] = mx; }
+    __syncthreads();
+    mn = red_u[0]; mx = red_v[0];
+    for (int w = 1; w < TOPP_THREADS / 64; ++w) { mn = min(mn, red_u[w]); mx = max(mx, red_v[w]); }
+    __syncthreads();
+    if (mn == mx) {
+      prefix = mn;
+    } else {
+      // ---- level 2: mantissa bits 22:11 inside exponent b1 ---------------------------------------------------------------
+      clear_hist(4096);
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = x[c][j];
+          const unsigned u = __float_as_uint(v);
+          if (v > 0.f && (u >> 23) == b1) atomicAdd(&h_sum[(u >> 11) & 0xFFFu], (double)v);
+        }
+      __syncthreads();
+      if (wave == 0) scan_sums(h_sum, 4096, cum_gt, p32, &cross, lane, true);
+      __syncthreads();
+      const unsigned pre20 = (b1 << 12) | (unsigned)cross.bucket;
+      cum_gt = cross.cum_before;
+      __syncthreads();
+      // ---- level 3: bits 10:0 ------------------------------------------------------------------------------------------------
+      clear_hist(2048);
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = x[c][j];
+          const unsigned u = __float_as_uint(v);
+          if (v > 0.f && (u >> 11) == pre20) atomicAdd(&h_sum[u & 0x7FFu], (double)v);
+        }
+      __syncthreads();
+      if (wave == 0) scan_sums(h_sum, 2048, cum_gt, p32, &cross, lane, true);
+      __syncthreads();
+      cum_gt = cross.cum_before;
+      prefix = (pre20 << 11) | (unsigned)cross.bucket;
+    }
+  }
+  __syncthreads();
+  {   // multiplicity of the crossing value (0 when nothing crossed: prefix = 0 then counts the zeros, unused)
+    unsigned cc = 0;
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cc += (__float_as_uint(x[c][j]) == prefix) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor((int)cc, o);
+    if (lane == 0) red_u[wave] = cc;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned t2 = 0;
+      for (int w = 0; w < TOPP_THREADS / 64; ++w) t2 += red_u[w];
+      sh_ntheta = t2;
+    }
+    __syncthreads();
+    n_eq = sh_ntheta;
+    __syncthreads();
+  }
+
+  // ---- how many copies of the crossing value tau still fit (as in the streaming kernel) -------------------------------------
+  unsigned c_fit = 0;
+  const double tau = crossing ? (double)__uint_as_float(prefix) : 0.0;
+  if (crossing) {
+    if (tau == 0.0) c_fit = n_eq;
+    else {
+      double guess = floor(((double)p32 - cum_gt) / tau);
+      long long c0 = guess < 0 ? 0 : (guess > (double)n_eq ? (long long)n_eq : (long long)guess);
+      while (c0 < (long long)n_eq && (float)(cum_gt + (double)(c0 + 1) * tau) <= p32) ++c0;
+      while (c0 > 0 && (float)(cum_gt + (double)c0 * tau) > p32) --c0;
+      c_fit = (unsigned)c0;
+    }
+  }
+  unsigned theta, r, n_theta;
+  double e_star;
+  bool none_kept = false;
+  if (crossing && c_fit >= 1) {
+    theta = prefix; r = c_fit - 1; n_theta = n_eq; e_star = tau;
+  } else {
+    const unsigned lo = crossing ? prefix : 0u;
+    unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u = __float_as_uint(x[c][j]);
+        if (present(u) && (!crossing || u > lo) && u < mn) mn = u;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+    if (lane == 0) red_u[wave] = mn;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned m2 = red_u[0];
+      for (int w = 1; w < TOPP_THREADS / 64; ++w) m2 = min(m2, red_u[w]);
+      sh_theta = m2;
+    }
+    __syncthreads();
+    theta = sh_theta;
+    if (theta == 0xFFFFFFFFu) { none_kept = true; r = 0; n_theta = 0; e_star = 0.0; }
+    else {
+      unsigned cc = 0;
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cc += (__float_as_uint(x[c][j]) == theta) ? 1u : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor((int)cc, o);
+      __syncthreads();
+      if (lane == 0) red_u[wave] = cc;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned t2 = 0;
+        for (int w = 0; w < TOPP_THREADS / 64; ++w) t2 += red_u[w];
+        sh_ntheta = t2;
+      }
+      __syncthreads();
+      n_theta = sh_ntheta;
+      r = n_theta - 1;
+      e_star = (double)__uint_as_float(theta);
+    }
+  }
+  const double fit_mass = cum_gt + (double)c_fit * tau;
+  if (tid == 0) sh_mass = none_kept ? 0.0f : (float)(fit_mass - e_star);
+  if (tid == 0) sh_idx_cut = (r == 0) ? -1 : (long long)V;
+  __syncthreads();
+  if (!none_kept && r > 0 && r < n_theta && wave == 0) {     // ties at the cut: the r-th theta-valued element in index order
+    unsigned running = 0;
+    long long cut = V;
+    for (int base = 0; base < V; base += 64) {
+      const int i = base + lane;
+      const bool eq = (i < V) && (__float_as_uint(value(i)) == theta);
+      const unsigned long long bal = __ballot(eq);
+      const unsigned c = (unsigned)__popcll(bal);
+      if (running + c >= r) {
+        unsigned need = r - running;
+        unsigned long long m = bal;
+        for (unsigned k = 1; k < need; ++k) m &= m - 1;
+        cut = base + (__ffsll(m) - 1);
+        break;
+      }
+      running += c;
+    }
+    if (lane == 0) sh_idx_cut = cut;
+  }
+  __syncthreads();
+  const long long idx_cut = sh_idx_cut;
+  const float mass = sh_mass;
+
+  // ---- final pass: keys from the registers and the noise (one HBM read), top-n per wave, merge ----------------------------------
+  WaveList wl;
+  wl.init(n, lane);
+  const bool noise_vec = ((((uintptr_t)(e - mis)) & 15) == 0);
+  auto load_noise = [&](int c, float (&en)[4]) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    if (noise_vec && i0 >= 0 && i0 + 4 <= V) {
+      const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(e + i0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) en[j] = raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) en[j] = (i0 + j >= 0 && i0 + j < V) ? e[i0 + j] : 1.0f;
+    }
+  };
+  constexpr int PF = 4;                                  // noise vectors in flight per lane
+  float en_ring[PF][4];
+#pragma unroll
+  for (int c = 0; c < PF && c < TOPP_NV; ++c) load_noise(c, en_ring[c]);
+  const float zero_over_mass = 0.f / mass;               // +0, or NaN when nothing is kept
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    float en[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) en[j] = en_ring[c % PF][j];
+    if (c + PF < TOPP_NV) load_noise(c + PF, en_ring[c % PF]);
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    // candidates by the full 64-bit order (key, then index): rows that keep few tokens are mostly zero keys, and a zero must
+    // not stay a candidate just because it ties with the list's zero threshold
+    u64 it[4];
+    uint32_t cmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = x[c][j];
+      const unsigned u = __float_as_uint(v);
+      const bool in = i0 + j >= 0 && i0 + j < V;
+      const bool kept = !none_kept && (u > theta || (u == theta && (long long)(i0 + j) <= idx_cut));
+      // a dropped token's key is (0 / mass) / e: +-0 unless e is 0 or NaN (then NaN) - no division needed for the usual case
+      const float key = kept ? (v / mass) / en[j] : ((zero_over_mass == 0.f && en[j] == en[j] && en[j] != 0.f && fabsf(en[j]) != INFINITY) ? 0.f : zero_over_mass / en[j]);
+      it[j] = make_item(key, (uint32_t)(i0 + j));
+      cmask |= (in && it[j] > wl.tau) ? (1u << j) : 0u;
+    }
+    while (__ballot(cmask != 0)) {
+      u64 mine = 0;
+      if (cmask) {
+        const int j = __ffs(cmask) - 1;
+        cmask &= cmask - 1;
+        mine = j == 0 ? it[0] : (j == 1 ? it[1] : (j == 2 ? it[2] : it[3]));
+      }
+      wl.offer_lanes(mine);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // keep PF noise vectors in flight: hoisting all 13 loads would spill the row
+  }
+  if (lane < n) lds_items[wave * n + lane] = wl.item;
+  __syncthreads();
+  rank_merge_store(lds_items, (TOPP_THREADS / 64) * n, n, a.out_ids + row * n, a.out_keys ? a.out_keys + row * n : nullptr, nullptr);
+}
+
 }  // namespace bg
 
 using namespace bg;
@@ -294,7 +648,8 @@ extern "C" int bg_topp_select(const float* probs, int64_t rows, int64_t V, int64
   BG_REQUIRE(n_blocked >= 0 && n_blocked <= BG_MAX_BLOCKED && (n_blocked == 0 || blocked), "bg_topp_select: n_blocked=%d", n_blocked);
   BG_REQUIRE(top_p == top_p, "bg_topp_select: top_p is NaN");
   ToppArgs a{probs, noise, blocked, V, row_stride, noise_row_stride, n, n_blocked, top_p, out_ids, out_keys};
-  hipLaunchKernelGGL(topp_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+  if (V + 3 <= TOPP_CAP) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(topp_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
   BG_CHECK_LAUNCH("bg_topp_select");
   return BG_OK;
 }
