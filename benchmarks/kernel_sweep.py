@@ -100,7 +100,8 @@ def sampling(rows, V):
             lse, lp = ops.softmax_stats(x, ids)
             gl, gp = torch.randn_like(lse), torch.randn_like(lp)
             return lambda: torch.autograd.grad((lse, lp), x, (gl, gp), retain_graph=True)
-        ms = timeit_graphed(make_bwd) if small else globals()['timeit'](make_bwd())
+        # (bf16 at rows <= 1024: capturing this backward crashed hipGraph instantiation on ROCm 7.2 - timed eagerly instead)
+        ms = timeit_graphed(make_bwd) if small and dt == torch.float32 else globals()['timeit'](make_bwd())
         report(f"softmax_stats_bwd rows={rows} V={V} {dt}", ms, 2 * rows * V * es)
     # reference op chain on the same GPU for scale (torch.argsort over V = what _topKSampling does)
     sub = probs[:1024]
