@@ -66,9 +66,14 @@ def test_tree_nodes_match_reference(golden, tag, family):
             np.testing.assert_allclose(n.valueHeadData["AlterationsValue"].cpu().numpy(), g[f"disc_node{i}_altV"], atol=5e-6)
 
 
+@pytest.mark.parametrize("schedule", ["one-pass", "node-by-node"])
 @pytest.mark.parametrize("tag,family", CASES)
-def test_train_step_losses_and_grads_match_reference(golden, tag, family):
-    from branchgan import configs
+def test_train_step_losses_and_grads_match_reference(golden, tag, family, schedule, monkeypatch):
+    """schedule "node-by-node": trees wider than one attention call can address (ops.MAX_SLOTS) take the fallbacks - the
+    generator re-forwards node by node with autograd, the discriminator runs root pass + tree pass separately."""
+    from branchgan import configs, ops
+    if schedule == "node-by-node":
+        monkeypatch.setattr(ops, "MAX_SLOTS", 0)
     g = golden("g35_" + tag)
     setup, conf, ids, sparse, calls = _setup(g, family)
     rl = configs.ReinforcementLearningConfig(labelMode=configs.ReinforcementLabelMode.ALTERATIONS_AND_INPUT_UNWEIGHTED,
