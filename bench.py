@@ -185,12 +185,14 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--no-tuned-gemm", action="store_true", help="hipBLASLt default heuristics instead of the recorded TunableOp choices")
     args = ap.parse_args()
     if os.environ.get("BRANCHGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BRANCHGAN_BENCH_WATCHDOG"]), exit=True)
 
     from branchgan import ops, training
+    tuned = (not args.no_tuned_gemm) and training.use_tuned_gemms()
     rank, world, local = training.init_data_parallel()
     if world != args.gpus and rank == 0:
         print(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; reporting n_gpus={world}", file=sys.stderr)
@@ -258,7 +260,7 @@ def main():
         "config": {"workload": wl["name"], "per_gpu_batch": B, "seq_len": S, "branch_points": wl["K"], "depth": wl["D"],
                    "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay of fwd+bwd; all-reduce and Adam eager",
                    "precision": "bf16 autocast, fp32 master weights and accumulation" if use_amp else "fp32",
-                   "weights": "random init", "final_losses": {"gen": float(g["loss"].detach()), "disc": float(d["loss"].detach())}},
+                   "weights": "random init", "gemm": "hipBLASLt, recorded TunableOp choices" if tuned else "hipBLASLt defaults", "final_losses": {"gen": float(g["loss"].detach()), "disc": float(d["loss"].detach())}},
         "roofline": roofline,
         "eager_event_ms": {k: {"launches": v[0], "avg_ms": round(v[1], 4)} for k, v in sorted(kernels.items())},   # includes host launch gaps
     }

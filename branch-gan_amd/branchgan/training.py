@@ -16,6 +16,29 @@ import torch
 import torch.distributed as dist
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning", "tunableop_gfx950_gpt2_small.csv")
+
+
+def use_tuned_gemms(path=TUNED_GEMMS):
+    """The dense GEMMs go through hipBLASLt; for the GPT-2-small shapes of BASELINE configs[1] its default heuristic is a few
+    percent off the best kernel it has.  This loads the choices a PYTORCH_TUNABLEOP tuning run recorded on an MI355X
+    (`branch-gan_amd/tuning/`, regenerate with PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py) and
+    turns tuning itself off, so nothing is timed at run time and unknown shapes keep the default.  A file recorded with another
+    hipBLASLt version is ignored by TunableOp's validators.  Returns whether the table was loaded."""
+    try:
+        import torch.cuda.tunable as tunable
+        if not (torch.cuda.is_available() and os.path.exists(path)):
+            return False
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.record_untuned_enable(False)
+        tunable.write_file_on_exit(False)
+        tunable.set_filename(path, insert_device_ordinal=False)
+        return bool(tunable.read_file(path))
+    except Exception:           # an optional speed-up: never a reason to fail
+        return False
+
+
 def worker_batch_size(batchSize, worldSize, rank):
     """SpawnedExperiment.py:63-68: floor(B / W), the remainder spread over the first ranks."""
     return batchSize // worldSize + (1 if rank < batchSize % worldSize else 0)
