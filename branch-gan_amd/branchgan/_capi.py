@@ -15,6 +15,7 @@ BG_F32, BG_BF16 = 0, 1
 MAX_TOPN, MAX_BLOCKED, MAX_SLOTS, MAX_GATHER = 64, 8, 64, 80
 
 c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+c_f64 = ctypes.c_double
 
 
 class AttnShape(ctypes.Structure):
@@ -61,6 +62,7 @@ SIGNATURES = {
     "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_i64, c_f64, c_i32, c_vp]),
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
     "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),

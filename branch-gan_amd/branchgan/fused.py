@@ -47,9 +47,31 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 _register_step_hook(_after_optimizer_step)
 
 
+_pinned = {}      # id(parameter) -> (weakref to it, low-precision copy, weakref to the optimizer that keeps the copy current)
+
+
+def pin_weight_copy(p, copy, owner):
+    """branchgan.optim.ArenaAdam writes the low-precision copy of each parameter in the same pass that updates it; such a
+    copy is always current, lives at a fixed address (safe to read from a captured graph) and is never re-cast here."""
+    import weakref
+    _pinned[id(p)] = (weakref.ref(p), copy, weakref.ref(owner))
+
+
+def _pinned_copy(p, dtype):
+    pin = _pinned.get(id(p))
+    if pin is None:
+        return None
+    if pin[0]() is not p or pin[2]() is None:        # the parameter or its optimizer is gone
+        del _pinned[id(p)]
+        return None
+    return pin[1] if pin[1].dtype == dtype else None
+
+
 def invalidate_weights():
     """Call after changing parameters by hand (load_state_dict, .data assignments) while a step is in flight."""
     _after_optimizer_step()
+    for owner in {id(o): o for o in (pin[2]() for pin in _pinned.values()) if o is not None}.values():
+        owner.refresh_weight_copies()
 
 
 def begin_capture():
@@ -77,6 +99,9 @@ def lowp(p, dtype):
     forward and backward of that step.  `prepare_weights` refreshes a whole model's copies with one multi-tensor launch."""
     if p.dtype == dtype:
         return p.detach()
+    pinned = _pinned_copy(p, dtype)
+    if pinned is not None:
+        return pinned
     hit = _cast_cache.get(id(p))
     if hit is not None and hit[0] is p and hit[1] == _cache_key(p) and hit[2].dtype == dtype:
         return hit[2]
@@ -97,7 +122,7 @@ def prepare_weights(module, dtype):
     pool = (capturing, _capture_epoch if capturing else 0)
     src, dst = [], []
     for p in module.parameters():
-        if p.dtype != torch.float32:
+        if p.dtype != torch.float32 or _pinned_copy(p, dtype) is not None:
             continue
         hit = _cast_cache.get(id(p))
         key = _cache_key(p)

@@ -90,14 +90,14 @@ class GraphedTrainStep:
     def _finish(self, stepCounter):
         for opt in (self.g_opt, self.d_opt):
             if stepCounter % opt.gradAccum == 0:
-                opt.arena.reduce_async()
+                opt.reduce_async()
         for opt in (self.g_opt, self.d_opt):
             opt.finish(stepCounter % opt.gradAccum == 0)
 
     def _start_update(self, opt, stepCounter, asynchronous):
         stepped = stepCounter % opt.gradAccum == 0
         if stepped:
-            opt.arena.reduce_async()
+            opt.reduce_async()
         (opt.finish_async if asynchronous else opt.finish)(stepped)
 
     def step(self, inputIDs, stepCounter):

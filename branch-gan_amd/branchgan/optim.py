@@ -1,0 +1,127 @@
+"""Adam over flat arenas - the optimizer half of the train step as one HBM-streaming launch per model.
+
+The reference builds `torch.optim.Adam(params, lr=lr)` (Training/Optimizers.py:6-16) and per optimizer step runs
+`optimizer.step(); optimizer.zero_grad()` (Optimizers.py:75-92); autocast then re-casts every weight to bf16 on its first use
+in the next forward.  On MI355X that is three passes over the model state per step (a multi-tensor Adam, a multi-tensor cast,
+a fill), ~3 ms of a 25 ms GPT-2-small step.  `ArenaAdam` keeps parameters, both moments and the bf16 weight copies in flat
+arenas next to branchgan.training.GradArena's flat gradients and updates all of them with ONE call of `bg_adam_step`
+(include/branchgan.h): read p, g, m, v; write p, m, v, bf16(p), g = 0.  Same mathematics and order of operations as
+torch.optim.Adam (amsgrad / maximize / capturable are not offered); the 1/world of the data-parallel mean is folded in.
+
+The bf16 copies are handed to branchgan.fused as "pinned" weight copies, so a fused forward (eager or captured in a HIP graph)
+reads them directly and never casts.
+"""
+import torch
+
+from . import _capi as C
+from . import fused
+
+
+class ArenaAdam(torch.optim.Optimizer):
+    zeroes_grads = True          # step() leaves every gradient it consumed at zero: no zero_grad pass afterwards
+    folds_grad_scale = True      # step() multiplies the gradient by `grad_scale`: the all-reduce may stay a plain sum
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lowp_dtype=torch.bfloat16):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("ArenaAdam: hyper-parameters out of range")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("ArenaAdam: one parameter group (one flat arena) only")
+        self.lowp_dtype = lowp_dtype
+        self.grad_scale = 1.0
+        self.steps = 0
+        self.grad_arena = None      # branchgan.training.GradArena, set by bind()
+        self.param_arena = self.exp_avg = self.exp_avg_sq = self.lowp_arena = None
+        self._outside = []
+
+    def bind(self, grad_arena):
+        """OptimizerWrapper hands over the model's GradArena: this optimizer steps exactly the parameters whose gradients
+        live in it, at the same offsets."""
+        self.grad_arena = grad_arena
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def _build(self):
+        ga = self.grad_arena
+        if ga is None:
+            raise RuntimeError("ArenaAdam: bind() a GradArena first (OptimizerWrapper does)")
+        if ga.arena is None:
+            ga._build()
+        own = {id(p) for p in self.param_groups[0]['params']}
+        if any(id(p) not in own for p in ga.params):
+            raise RuntimeError("ArenaAdam: the gradient arena holds parameters this optimizer was not given")
+        for p in ga.params:
+            if p.dtype != torch.float32 or not p.is_cuda:
+                raise RuntimeError("ArenaAdam: fp32 parameters on the GPU only")
+        n, dev = ga.arena.numel(), ga.arena.device
+        self.param_arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(ga.params, ga.offsets):
+                view = self.param_arena[off:off + p.numel()].view(p.shape)
+                view.copy_(p.detach())
+                p.data = view
+        inside = {id(p) for p in ga.params}
+        self._outside = [p for p in self.param_groups[0]['params'] if id(p) not in inside]
+        if self.lowp_dtype is not None:
+            self.lowp_arena = self.param_arena.to(self.lowp_dtype)
+            for p, off in zip(ga.params, ga.offsets):
+                fused.pin_weight_copy(p, self.lowp_arena[off:off + p.numel()].view(p.shape), self)
+        fused.invalidate_weights()
+
+    def refresh_weight_copies(self):
+        """After parameters were changed by hand (load_state_dict, .data edits): re-round the low-precision copies."""
+        if self.lowp_arena is not None:
+            self.lowp_arena.copy_(self.param_arena)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self.param_arena is None:
+            self._build()
+        for p in self._outside:
+            if p.grad is not None:
+                raise RuntimeError("ArenaAdam: a parameter received its first gradient after the arenas were laid out "
+                                   f"(shape {tuple(p.shape)}); every trained parameter needs a gradient in the first step")
+        g = self.param_groups[0]
+        self.steps += 1
+        lp = self.lowp_arena
+        C.check(C.lib().bg_adam_step(C.ptr(self.param_arena), C.ptr(self.grad_arena.arena), C.ptr(self.exp_avg), C.ptr(self.exp_avg_sq),
+                                     C.ptr(lp), C.dtype_code(lp) if lp is not None else 0, self.param_arena.numel(),
+                                     float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                     float(g['weight_decay']), self.steps, float(self.grad_scale), 1, C.stream_ptr()), "bg_adam_step")
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        if self.grad_arena is not None and self.grad_arena.arena is not None:
+            self.grad_arena.arena.zero_()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # torch.optim.Adam's state layout, so checkpoints move between the two ------------------------------------------------
+    def state_dict(self):
+        if self.param_arena is not None:
+            step = torch.tensor(float(self.steps))
+            for p, off in zip(self.grad_arena.params, self.grad_arena.offsets):
+                sl = slice(off, off + p.numel())
+                self.state[p] = {'step': step.clone(), 'exp_avg': self.exp_avg[sl].view(p.shape), 'exp_avg_sq': self.exp_avg_sq[sl].view(p.shape)}
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if not self.state:
+            return
+        if self.param_arena is None:
+            raise RuntimeError("ArenaAdam.load_state_dict: run one step first (the arenas are laid out by the first step)")
+        with torch.no_grad():
+            for p, off in zip(self.grad_arena.params, self.grad_arena.offsets):
+                st = self.state.get(p)
+                if st:
+                    sl = slice(off, off + p.numel())
+                    self.exp_avg[sl].view(p.shape).copy_(st['exp_avg'])
+                    self.exp_avg_sq[sl].view(p.shape).copy_(st['exp_avg_sq'])
+                    self.steps = int(float(st['step']))
+        self.state.clear()

@@ -32,7 +32,9 @@ def use_tuned_gemms(path=TUNED_GEMMS):
         tunable.enable(True)
         tunable.tuning_enable(False)
         tunable.record_untuned_enable(False)
-        tunable.write_file_on_exit(False)
+        keep = getattr(torch._C, "_cuda_tunableop_write_file_on_exit", None)
+        if keep is not None:
+            keep(False)           # read-only use of the table
         tunable.set_filename(path, insert_device_ordinal=False)
         return bool(tunable.read_file(path))
     except Exception:           # an optional speed-up: never a reason to fail
@@ -67,21 +69,22 @@ class GradArena:
     def __init__(self, module, bucket_bytes=64 << 20, group=None):
         self.module, self.bucket_bytes, self.group = module, bucket_bytes, group
         self.arena = None
-        self.params = []
+        self.params, self.offsets = [], []
         self.stream = None
         self._work = []
 
     def _build(self):
         self.params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = [], 0
+        for p in self.params:                 # every parameter starts on a 32-byte boundary (16-byte vectors in fp32 and bf16)
+            self.offsets.append(n)
+            n += (p.numel() + 7) & ~7
         dev = self.params[0].device
         self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             view = self.arena[off:off + p.numel()].view_as(p)
             view.copy_(p.grad)
             p.grad = view
-            off += p.numel()
         if dev.type == "cuda":
             self.stream = torch.cuda.Stream(device=dev)
 
@@ -95,8 +98,9 @@ class GradArena:
     def nbytes(self):
         return 0 if self.arena is None else self.arena.numel() * 4
 
-    def reduce_async(self):
-        """Call after backward.  Launches the bucketed all-reduce; `wait()` before the optimizer step."""
+    def reduce_async(self, average=True):
+        """Call after backward.  Launches the bucketed all-reduce; `wait()` before the optimizer step.  average=False leaves
+        the SUM over ranks in the arena (an optimizer that folds 1/world into its update, optim.ArenaAdam)."""
         if self.arena is None:
             self._build()
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -108,11 +112,13 @@ class GradArena:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 for b in buckets:
-                    b.div_(world)
+                    if average:
+                        b.div_(world)
                     self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             for b in buckets:
-                b.div_(world)
+                if average:
+                    b.div_(world)
                 self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
@@ -130,19 +136,34 @@ class OptimizerWrapper:
     def __init__(self, model, optimizer, gradAccum=1, lossKey='loss', scheduler=None, arena=None):
         self.model, self.optimizer, self.gradAccum, self.lossKey, self.scheduler = model, optimizer, gradAccum, lossKey, scheduler
         self.arena = arena if arena is not None else GradArena(model)
+        if hasattr(optimizer, "bind"):             # optim.ArenaAdam lays its own arenas out next to the gradient arena
+            optimizer.bind(self.arena)
+
+    def reduce_async(self):
+        """Starts the gradient all-reduce of an optimizer step.  The mean over ranks is either taken here or, for an
+        optimizer that says so, folded into its update."""
+        folds = getattr(self.optimizer, "folds_grad_scale", False)
+        if folds:
+            world = dist.get_world_size(self.arena.group) if dist.is_initialized() else 1
+            self.optimizer.grad_scale = 1.0 / world
+        self.arena.reduce_async(average=not folds)
+
+    def _step_and_zero(self):
+        self.optimizer.step()
+        if not getattr(self.optimizer, "zeroes_grads", False):
+            self.arena.zero()
 
     def backward(self, losses, stepCounter):
         losses[self.lossKey].backward()
         if stepCounter % self.gradAccum == 0:
-            self.arena.reduce_async()
+            self.reduce_async()
             return True
         return False
 
     def finish(self, stepped):
         if stepped:
             self.arena.wait()
-            self.optimizer.step()
-            self.arena.zero()
+            self._step_and_zero()
             if self.scheduler is not None:
                 self.scheduler.step()
 
@@ -158,8 +179,7 @@ class OptimizerWrapper:
             for w in self.arena._work:
                 w.wait()
             self.arena._work = []
-            self.optimizer.step()
-            self.arena.zero()
+            self._step_and_zero()
         if self.scheduler is not None:
             self.scheduler.step()
 
@@ -175,6 +195,10 @@ def make_optimizer(params, name='adam', lr=1e-4, **kw):
     """Optimizers.py:6-16 (NAME_TO_OPTIM)."""
     table = {'adam': torch.optim.Adam, 'adagrad': torch.optim.Adagrad, 'sgd': torch.optim.SGD, 'rmsprop': torch.optim.RMSprop}
     params = list(params)
+    if name.lower() == 'adam' and params and params[0].is_cuda and all(isinstance(p, torch.Tensor) for p in params) \
+            and set(kw) <= {'betas', 'eps', 'weight_decay'} and os.environ.get("BRANCHGAN_ARENA_ADAM", "1") != "0":
+        from .optim import ArenaAdam
+        return ArenaAdam(params, lr=lr, **kw)     # one streaming launch per step: update + bf16 weight copies + zeroed gradients
     if name.lower() == 'adam' and 'fused' not in kw and params and params[0].is_cuda:
         kw['fused'] = True        # one multi-tensor kernel per step instead of a chain of foreach launches
     return table[name.lower()](params, lr=lr, **kw)

@@ -187,6 +187,22 @@ int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_r
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Adam over flat arenas: one streaming launch per optimizer step.  Replaces, per model, the reference's
+ * torch.optim.Adam step over every parameter tensor, the gradient zeroing that follows it
+ * (Training/Optimizers.py:6-16 NAME_TO_OPTIM, :75-92 performUpdateStep: optimizer.step(); optimizer.zero_grad()) and
+ * the fp32 -> bf16 weight casts autocast issues on the next forward.
+ *   param, grad, exp_avg, exp_avg_sq: fp32 [n], 16-byte aligned, updated in place with torch's order of operations:
+ *     g = grad * grad_scale (+ weight_decay * param);  exp_avg += (g - exp_avg) * (1 - beta1);
+ *     exp_avg_sq = exp_avg_sq * beta2 + (1 - beta2) * g * g;
+ *     param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps)
+ *   param_lp (optional, bf16 [n]): the updated parameters rounded to nearest even; zero_grad != 0: grad = 0 afterwards.
+ *   step counts from 1.  grad_scale folds the 1 / world of a summed all-reduce into the same pass.
+ */
+int bg_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* param_lp, int lp_dtype, int64_t n,
+                 double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                 double grad_scale, int zero_grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused discriminator losses.  Replaces Models/Losses/DiscriminatorLoss.py:4-74 (≈60 ATen launches).
  *   input_scores fp32 [B][S]; alt_scores fp32 [B][N][K] (the K real columns; the reference's zero padding
  *   to S is implicit); depth_mask fp32 [N][K]; txt_in, txt_alt fp32 [B][S]; alt_alt fp32 [N][B][K];

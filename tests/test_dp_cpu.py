@@ -39,7 +39,9 @@ def _worker(rank, world, port, tmp):
     for step in range(4):
         loss = ((model(data[lo:lo + b]) - target[lo:lo + b]) ** 2).mean()
         opt.performUpdateStep({"loss": loss}, step)
-    assert model.unused.weight.grad is None and opt.arena.arena.numel() == 6 * 5 + 5 + 5 + 1
+    pad8 = lambda n: (n + 7) & ~7                      # every parameter starts on a 32-byte boundary of the arena
+    assert model.unused.weight.grad is None and opt.arena.arena.numel() == pad8(6 * 5) + pad8(5) + pad8(5) + pad8(1)
+    assert opt.arena.offsets == [0, 32, 40, 48]
     torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
