@@ -36,9 +36,8 @@ __device__ __forceinline__ void adam_one(const AdamArgs& a, float& p, float g, f
 }
 
 #define ADAM_THREADS 256
-#define ADAM_U 2   // 16-byte vectors per array per thread per iteration: 8 loads in flight per lane
-
-template <bool HAS_LP>
+// ADAM_U: 16-byte vectors per array per thread per iteration; NT: nontemporal loads / stores for the streamed arrays
+template <bool HAS_LP, int ADAM_U, bool NT>
 __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(AdamArgs a) {
   const int64_t nvec = a.n >> 2;
   const int64_t stride = (int64_t)gridDim.x * ADAM_THREADS;
@@ -54,10 +53,14 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(AdamArgs a) {
     for (int u = 0; u < ADAM_U; ++u) {
       const int64_t i = i0 + u * stride;
       if (i < nvec) {
-        p[u] = __builtin_nontemporal_load(P + i);
-        g[u] = __builtin_nontemporal_load(G + i);
-        m[u] = __builtin_nontemporal_load(M + i);
-        v[u] = __builtin_nontemporal_load(V + i);
+        if (NT) {
+          p[u] = __builtin_nontemporal_load(P + i);
+          g[u] = __builtin_nontemporal_load(G + i);
+          m[u] = __builtin_nontemporal_load(M + i);
+          v[u] = __builtin_nontemporal_load(V + i);
+        } else {
+          p[u] = P[i], g[u] = G[i], m[u] = M[i], v[u] = V[i];
+        }
       }
     }
 #pragma unroll
@@ -70,10 +73,15 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(AdamArgs a) {
           adam_one(a, pj, g[u][j], mj, vj);
           p[u][j] = pj, m[u][j] = mj, v[u][j] = vj;
         }
-        __builtin_nontemporal_store(p[u], P + i);
-        __builtin_nontemporal_store(m[u], M + i);
-        __builtin_nontemporal_store(v[u], V + i);
-        if (a.zero_grad) __builtin_nontemporal_store(zero, G + i);
+        if (NT) {
+          __builtin_nontemporal_store(p[u], P + i);
+          __builtin_nontemporal_store(m[u], M + i);
+          __builtin_nontemporal_store(v[u], V + i);
+          if (a.zero_grad) __builtin_nontemporal_store(zero, G + i);
+        } else {
+          P[i] = p[u], M[i] = m[u], V[i] = v[u];
+          if (a.zero_grad) G[i] = zero;
+        }
         if (HAS_LP) {
           bf16x4 l;
 #pragma unroll
@@ -118,13 +126,15 @@ extern "C" int bg_adam_step(float* param, float* grad, float* exp_avg, float* ex
   a.one_minus_beta1 = (float)(1.0 - beta1), a.beta2 = (float)beta2, a.one_minus_beta2 = (float)(1.0 - beta2), a.eps = (float)eps, a.weight_decay = (float)weight_decay;
   a.grad_scale = (float)grad_scale;
   a.zero_grad = zero_grad;
-  const int64_t per_block = (int64_t)ADAM_THREADS * ADAM_U * 4;
-  const unsigned grid = (unsigned)(cdiv(n, per_block) < 4096 ? cdiv(n, per_block) : 4096);
+  // one 16-byte vector of each array per thread and no grid-stride loop: measured 5.8 TB/s on a 124M-parameter arena against
+  // 4.5 TB/s for 4096 looping workgroups (the streams of a looping workgroup drift apart across HBM channels)
+  const int64_t per_block = (int64_t)ADAM_THREADS * 4;
+  const unsigned grid = (unsigned)(cdiv(n, per_block) < (1 << 24) ? cdiv(n, per_block) : (1 << 24));
   hipStream_t st = (hipStream_t)stream;
   if (param_lp)
-    hipLaunchKernelGGL(adam_step_kernel<true>, dim3(grid), dim3(ADAM_THREADS), 0, st, a);
+    hipLaunchKernelGGL((adam_step_kernel<true, 1, true>), dim3(grid), dim3(ADAM_THREADS), 0, st, a);
   else
-    hipLaunchKernelGGL(adam_step_kernel<false>, dim3(grid), dim3(ADAM_THREADS), 0, st, a);
+    hipLaunchKernelGGL((adam_step_kernel<false, 1, true>), dim3(grid), dim3(ADAM_THREADS), 0, st, a);
   BG_CHECK_LAUNCH("bg_adam_step");
   return BG_OK;
 }
