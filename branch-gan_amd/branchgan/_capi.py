@@ -62,6 +62,9 @@ SIGNATURES = {
     "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_embed_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "bg_embed_bwd_workspace_bytes": (c_sz, [c_i64]),
+    "bg_embed_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "bg_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_i64, c_f64, c_i32, c_vp]),
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),

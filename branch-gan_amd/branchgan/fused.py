@@ -251,6 +251,54 @@ def add_layer_norm(x, delta, ln, out_dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Token + position embedding
+# ---------------------------------------------------------------------------------------------------------------------
+class _Embedding(torch.autograd.Function):
+    """wte[ids] + wpe[pos] in one launch; backward adds into both tables' fp32 gradients deterministically."""
+
+    @staticmethod
+    def forward(ctx, ids, pos, wte, wpe):
+        rows, C_ = ids.numel(), wte.shape[1]
+        out = torch.empty(ids.shape + (C_,), dtype=torch.float32, device=wte.device)
+        with ops._timed("embed_fwd"):
+            C.check(C.lib().bg_embed_fwd(C.ptr(ids), rows, C.ptr(pos), pos.numel(), C.ptr(wte.detach()), wte.shape[0],
+                                         C.ptr(wpe.detach()), wpe.shape[0], C_, C.ptr(out), C.stream_ptr()), "bg_embed_fwd")
+        ctx.save_for_backward(ids, pos)
+        ctx.params = (wte, wpe)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, pos = ctx.saved_tensors
+        rows = ids.numel()
+        dy2 = dy.reshape(rows, -1).contiguous().float()
+        lib = C.lib()
+        ws = _workspace(lib.bg_embed_bwd_workspace_bytes(rows), dy2.device)
+        rets = []
+        with ops._timed("embed_bwd"):
+            for table, idx in zip(ctx.params, (ids, pos)):
+                if not table.requires_grad:
+                    rets.append(None)
+                    continue
+                buf, ret = _grad_buffer(table)
+                C.check(lib.bg_embed_bwd(C.ptr(dy2), C.ptr(idx), rows, idx.numel(), table.shape[0], dy2.shape[1], C.ptr(buf),
+                                         C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_embed_bwd")
+                rets.append(ret)
+        return None, None, rets[0], rets[1]
+
+
+def embedding(input_ids, pos, wte, wpe):
+    """input_ids (B, T) integer; pos (B, T) or (1, T) integer, possibly an expanded view -> fp32 (B, T, C)."""
+    ids = input_ids.contiguous().long()
+    if pos.dim() == 2 and pos.shape[0] > 1 and pos.stride(0) == 0:
+        pos = pos[0]                                   # one row of positions shared by the batch: rows index it modulo T
+    pos = pos.contiguous().long().view(-1)
+    if ids.numel() % pos.numel() != 0:
+        raise ValueError("embedding: positions do not tile the ids")
+    return _Embedding.apply(ids, pos, wte, wpe)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Linear (+ GELU) with in-place gradient accumulation
 # ---------------------------------------------------------------------------------------------------------------------
 _ACT = {None: 0, "gelu_tanh": 1, "gelu": 2}

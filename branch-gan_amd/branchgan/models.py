@@ -479,7 +479,7 @@ class NonResidualGPT2LMHeadModel(_LMBase):
             dtype = fused.compute_dtype(tr.wte.weight)
             fused.prepare_weights(self, dtype)
             with torch.autocast("cuda", enabled=False):
-                x, delta, presents = tr.wte(input_ids) + tr.wpe(pos.long()), None, []
+                x, delta, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, []
                 for i, block in enumerate(tr.h):
                     x, delta, present = block.fused_forward(x, delta, dtype, _layer_past(textualPast, i) if branch else None)
                     presents.append(present)

@@ -187,6 +187,25 @@ int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_r
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Token + position embedding of the GPT-2 family.  Replaces `wte(input_ids) + wpe(position_ids)` of the reference's
+ * model forward (Models/GPT2BranchAttention/NonResidualDiscriminatorBase.py:300-330; two ATen gathers + an add) and the
+ * two embedding_dense_backward calls + AccumulateGrad adds autograd runs for it.
+ * bg_embed_fwd:  out[r] = wte[ids[r]] + wpe[pos[r % pos_rows]]   (pos may be NULL: token table only).
+ *   ids int64 [rows]; pos int64 [pos_rows] (pos_rows divides the broadcast: [T] positions shared by B sequences);
+ *   wte fp32 [vocab][C]; wpe fp32 [n_pos][C]; out fp32 [rows][C]; C % 4 == 0.
+ *   A row whose index is outside its table comes back NaN (the reference raises IndexError; a kernel cannot).
+ * bg_embed_bwd:  dW[idx[r % idx_rows]] += dy[r] for every row, DETERMINISTIC (no atomics: the rows that share an
+ *   index are added in ascending row order by the workgroup of the lowest such row) and accumulating into the
+ *   fp32 gradient.  dy fp32 [rows][C]; idx int64 [idx_rows]; dW fp32 [table_rows][C]; rows with an index outside the
+ *   table are skipped.  workspace: bg_embed_bwd_workspace_bytes(rows), 4-byte aligned.
+ */
+int bg_embed_fwd(const int64_t* ids, int64_t rows, const int64_t* pos, int64_t pos_rows, const float* wte, int64_t vocab,
+                 const float* wpe, int64_t n_pos, int C, float* out, void* stream);
+size_t bg_embed_bwd_workspace_bytes(int64_t rows);
+int bg_embed_bwd(const float* dy, const int64_t* idx, int64_t rows, int64_t idx_rows, int64_t table_rows, int C, float* dW,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam over flat arenas: one streaming launch per optimizer step.  Replaces, per model, the reference's
  * torch.optim.Adam step over every parameter tensor, the gradient zeroing that follows it
  * (Training/Optimizers.py:6-16 NAME_TO_OPTIM, :75-92 performUpdateStep: optimizer.step(); optimizer.zero_grad()) and
