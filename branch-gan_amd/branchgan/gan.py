@@ -37,11 +37,17 @@ class GannSetup(torch.nn.Module):
         pos = torch.stack([n.sparseIndex + n.depth for n in alternationNodes]).to(inputIDs.device)
         return torch.less_equal(pos, inputIDs.shape[-1] - 1).float()
 
-    def _multiStepForwardPass(self, inputIDs, samplingConf, collectTreeDepthData=True):
+    def _generatorForward(self, inputIDs, samplingConf):
+        """The generator's half of the forward pass (GanSetup.py:140-150 multiStepGenForward): root pass, branch sampling and
+        the branch log-probabilities.  It touches no discriminator weight, so a caller may run it while the discriminator's
+        optimizer step of the previous train step is still in flight (graphs.GraphedTrainStep does)."""
         sparseIndex = samplingConf.getSparseIndex(inputIDs, self.generatorDevice)
-        root, firstPred, probs, firstMaskedProbs = MultiStepPrediction.multiStepGenForward(
+        return MultiStepPrediction.multiStepGenForward(
             self.generator, inputIDs, samplingConf.rules, self.generatorDevice, sparseIndex=sparseIndex, clearTreePast=True,
             noise_fn=self.noise_fn)
+
+    def _multiStepForwardPass(self, inputIDs, samplingConf, collectTreeDepthData=True, generatorState=None):
+        root, firstPred, probs, firstMaskedProbs = generatorState if generatorState is not None else self._generatorForward(inputIDs, samplingConf)
         nodes = root.getSubNodes() if samplingConf.includeAllMultiStepSamplesForDisc else root.getLeaves()
         if samplingConf.discDepthLossSchedule is not None or samplingConf.discpDepthLossWeight is not None:
             raise NotImplementedError("depth loss schedules are undefined in the reference (quirk 14)")
@@ -67,7 +73,7 @@ class GannSetup(torch.nn.Module):
         samplingConf = self.samplingConf if samplingConf is None else samplingConf
         if kwargs.get('mixedPrecision', False):
             raise NotImplementedError("fp16 autocast + GradScaler is replaced by a bf16 model dtype (SURVEY §2 #15)")
-        return self._multiStepForwardPass(inputIDs, samplingConf)
+        return self._multiStepForwardPass(inputIDs, samplingConf, generatorState=kwargs.get('generatorState'))
 
     def _internalTrainForwardPass(self, inputIDs, samplingConf, numNegativeUpdateSamples=1, **kwargs):
         samplingConf = self.samplingConf if samplingConf is None else samplingConf

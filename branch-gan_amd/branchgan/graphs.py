@@ -2,7 +2,7 @@
 
 One Branch-GAN step is thousands of small launches (a GPT-2-small step at depth 4 issues ~5k kernels for ~50 ms of GPU work),
 so the host cannot keep the queue full.  The forward of the whole GAN step and both backward passes are captured ONCE into a
-hipGraph (torch.cuda.graph) and replayed per step; inputs (token ids, branch points) live in static device tensors that are
+set of hipGraphs (torch.cuda.graph) and replayed per step; inputs (token ids, branch points) live in static device tensors that are
 overwritten before each replay, gradients accumulate into the static flat arenas of branchgan.training.GradArena.
 The gradient all-reduce (RCCL) and the optimizer steps stay outside the graph, so the data-parallel path is unchanged.
 The reference has no counterpart (it is eager PyTorch); results are identical to the eager step by construction.
@@ -43,6 +43,8 @@ class GraphedTrainStep:
         self.graph = None
         self.losses = None
         self._sync = _sync_after_replay()
+        self._defer_d = self._sync if os.environ.get("BRANCHGAN_DEFER_D") is None else os.environ["BRANCHGAN_DEFER_D"] == "1"
+        self._pending_d = None
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
         self._refresh_sparse(example_ids)
         side = torch.cuda.Stream(device=dev)
@@ -54,15 +56,19 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
-        # two graphs: [forward of everything + generator backward] and [discriminator backward].  Between them the
-        # generator's gradient all-reduce and Adam step start on a side stream and run behind the second graph.
+        # three graphs: [generator forward], [discriminator forward + losses + generator backward], [discriminator backward];
+        # see step() for what runs between them.
+        self.graph_g = torch.cuda.CUDAGraph()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_d = torch.cuda.CUDAGraph()
         fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # collective backends run helper threads
-            self.losses = self._forward()
+        with torch.cuda.graph(self.graph_g, capture_error_mode="thread_local"):   # collective backends run helper threads
+            with self._autocast():
+                self.gen_state = self.model._generatorForward(self.static_ids, self.conf)
+        with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), capture_error_mode="thread_local"):
+            self.losses = self._forward(self.gen_state)
             self.losses[1][self.g_opt.lossKey].backward()
-        with torch.cuda.graph(self.graph_d, pool=self.graph.pool(), capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), capture_error_mode="thread_local"):
             self.losses[0][self.d_opt.lossKey].backward()
         ops.TIMING = timing
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
@@ -76,10 +82,14 @@ class GraphedTrainStep:
             sp = torch.arange(ids.shape[1], device=ids.device)
         self.static_sparse.copy_(sp.to(self.static_sparse.device), non_blocking=True)
 
-    def _forward(self):
-        with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+    def _autocast(self):
+        return torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None)
+
+    def _forward(self, generatorState=None):
+        with self._autocast():
             return self.model.trainForwardPassNoMetrics(self.static_ids, self.conf, self.n_update, collectTreeDepthData=False,
-                                                        reinforcementLearningConfig=self.rl, checkNaN=False)
+                                                        reinforcementLearningConfig=self.rl, checkNaN=False,
+                                                        generatorState=generatorState)
 
     def _forward_backward(self):
         d, g = self._forward()
@@ -94,30 +104,53 @@ class GraphedTrainStep:
         for opt in (self.g_opt, self.d_opt):
             opt.finish(stepCounter % opt.gradAccum == 0)
 
-    def _start_update(self, opt, stepCounter, asynchronous):
+    def _reduce(self, opt, stepCounter):
         stepped = stepCounter % opt.gradAccum == 0
         if stepped:
             opt.reduce_async()
-        (opt.finish_async if asynchronous else opt.finish)(stepped)
+        return stepped
+
+    def _finish_pending(self):
+        if self._pending_d is not None:
+            self.d_opt.finish(self._pending_d)
+            self._pending_d = None
 
     def step(self, inputIDs, stepCounter):
         """One train step: returns the (static) loss dicts; GanSetup.py:249-256's NaN guard is evaluated on the device and
-        raised by check_nan() (one host sync when the caller chooses, not one per loss key per step)."""
+        raised by check_nan() (one host sync when the caller chooses, not one per loss key per step).
+
+        Schedule: only the gradient all-reduces overlap compute - the generator's runs behind the discriminator's backward
+        graph, the discriminator's behind the NEXT step's generator-forward graph (which reads no discriminator weight), so
+        with more than one rank the discriminator's optimizer step is deferred to the next call (or `join()`).  The Adam
+        launches themselves stay on the main stream: measured on MI355X, an Adam pass (121k workgroups streaming 4 GB)
+        running beside a replaying graph costs 0.8 ms per step more than it hides."""
         self.static_ids.copy_(inputIDs, non_blocking=True)
         self._refresh_sparse(inputIDs)
-        self.graph.replay()                                # forward + generator backward
+        self.graph_g.replay()                              # generator forward
+        self._finish_pending()                             # D's all-reduce of the last step is done by now: its Adam step
+        self.graph.replay()                                # discriminator forward + losses + generator backward
         if self._sync:
             torch.cuda.current_stream().synchronize()
         d, g = self.losses
-        self._start_update(self.g_opt, stepCounter, asynchronous=True)
-        self.graph_d.replay()                              # discriminator backward, with G's all-reduce + Adam behind it
+        g_stepped = self._reduce(self.g_opt, stepCounter)
+        self.graph_d.replay()                              # discriminator backward, G's all-reduce behind it
         if self._sync:
             torch.cuda.current_stream().synchronize()
         self.nan_flag |= torch.isnan(g['loss'].detach())
-        self._start_update(self.d_opt, stepCounter, asynchronous=False)
-        self.g_opt.join()
+        self.g_opt.finish(g_stepped)
+        d_stepped = self._reduce(self.d_opt, stepCounter)
+        if self._defer_d:
+            self._pending_d = d_stepped
+        else:
+            self.d_opt.finish(d_stepped)
         return d, g
 
+    def join(self):
+        """With more than one rank the discriminator's optimizer step of the last `step()` is still pending: call this
+        before anything outside `step()` reads the discriminator's parameters."""
+        self._finish_pending()
+
     def check_nan(self):
+        self.join()
         if bool(self.nan_flag):
             raise Exception("Generator loss loss is NaN")
