@@ -59,7 +59,7 @@ SIGNATURES = {
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
-    "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_embed_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),

@@ -181,20 +181,21 @@ def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype):
     return x_out, y, mean, rstd
 
 
-def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype):
+def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None):
     rows, C_ = x2.shape
     dx = torch.empty_like(x2)
     dx_lp = torch.empty((rows, C_), dtype=lp_dtype, device=x2.device) if lp_dtype not in (None, torch.float32) else None
     dg, dg_ret = _grad_buffer(gamma_p)
     db, db_ret = _grad_buffer(beta_p)
+    dc, dc_ret = _grad_buffer(colsum_p) if colsum_p is not None else (None, None)
     lib = C.lib()
     nbytes = lib.bg_layernorm_bwd_workspace_bytes(rows, C_)
     ws = _workspace(nbytes, x2.device)
     with ops._timed("layernorm_bwd"):
         C.check(lib.bg_layernorm_bwd(C.ptr(dy2), C.dtype_code(dy2), C.ptr(x2), C.ptr(mean), C.ptr(rstd), C.ptr(gamma_p.detach()),
                                      C.ptr(dres2), rows, C_, C.ptr(dx), C.ptr(dx_lp), C.dtype_code(dx_lp) if dx_lp is not None else 0,
-                                     C.ptr(dg), C.ptr(db), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
-    return dx, dx_lp, dg_ret, db_ret
+                                     C.ptr(dg), C.ptr(db), C.ptr(dc), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
+    return dx, dx_lp, dg_ret, db_ret, dc_ret
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -210,18 +211,21 @@ class _LayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
-        dx, _, dg, db = _ln_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, gamma, beta, None, None)
+        dx, _, dg, db, _ = _ln_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, gamma, beta, None, None)
         return dx.view(dy.shape), dg, db, None, None
 
 
 class _AddLayerNorm(torch.autograd.Function):
+    """delta_bias (optional): the bias parameter of the projection that produced `delta`.  Its gradient is the column sum of
+    delta's gradient, which this backward has in registers anyway - the projection is then built with bias_grad=False."""
+
     @staticmethod
-    def forward(ctx, x, delta, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         d2 = delta.reshape(x2.shape).contiguous()
         x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype)
         ctx.save_for_backward(x_out, mean, rstd)
-        ctx.params = (gamma, beta)
+        ctx.params = (gamma, beta, delta_bias)
         ctx.delta_dtype = delta.dtype
         ctx.set_materialize_grads(False)
         return x_out.view(x.shape), y.view(x.shape)
@@ -229,25 +233,33 @@ class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx_new, dy):
         x_out, mean, rstd = ctx.saved_tensors
-        gamma, beta = ctx.params
+        gamma, beta, delta_bias = ctx.params
+        if delta_bias is not None and not delta_bias.requires_grad:
+            delta_bias = None
         if dy is None and dx_new is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if dy is None:      # only the residual output was used
             dres = dx_new.reshape(x_out.shape).contiguous().float()
-            return dres.view(dx_new.shape), dres.to(ctx.delta_dtype).view(dx_new.shape), None, None, None, None
+            dlp = dres.to(ctx.delta_dtype)
+            dc_ret = None
+            if delta_bias is not None:
+                buf, dc_ret = _grad_buffer(delta_bias)
+                buf.add_(dlp.float().sum(0))
+            return dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret
         dres2 = dx_new.reshape(x_out.shape).contiguous().float() if dx_new is not None else None
-        dx, dx_lp, dg, db = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype)
+        dx, dx_lp, dg, db, dc = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype,
+                                        delta_bias)
         shape = dy.shape
-        return dx.view(shape), (dx_lp if dx_lp is not None else dx).view(shape), dg, db, None, None
+        return dx.view(shape), (dx_lp if dx_lp is not None else dx).view(shape), dg, db, None, None, dc
 
 
 def layer_norm(x, ln, out_dtype):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype)
 
 
-def add_layer_norm(x, delta, ln, out_dtype):
-    """-> (x + delta [fp32], LayerNorm(x + delta) [out_dtype])"""
-    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype)
+def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None):
+    """-> (x + delta [fp32], LayerNorm(x + delta) [out_dtype]).  delta_bias: see _AddLayerNorm."""
+    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -335,7 +347,7 @@ class _Linear(torch.autograd.Function):
     """y = act(x @ W + b).  layout 'io': W is (in, out) (GPT-2 Conv1D); 'oi': (out, in) (nn.Linear)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, layout, act, dtype):
+    def forward(ctx, x, weight, bias, layout, act, dtype, bias_grad):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.dtype != dtype:
             x2 = x2.to(dtype)
@@ -347,7 +359,7 @@ class _Linear(torch.autograd.Function):
         else:
             y = F.gelu(pre, approximate="tanh" if act == "gelu_tanh" else "none")
         ctx.save_for_backward(x2, pre if act is not None else None)
-        ctx.meta = (weight, bias, layout, act, dtype, x.shape)
+        ctx.meta = (weight, bias if bias_grad else None, layout, act, dtype, x.shape)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -383,11 +395,12 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, w.t() if layout == "io" else w).view(in_shape)
         dw_ret = _accumulate_matmul(weight, x2.t(), dy2) if layout == "io" else _accumulate_matmul(weight, dy2.t(), x2)
-        return dx, dw_ret, db_ret, None, None, None
+        return dx, dw_ret, db_ret, None, None, None, None
 
 
-def linear(x, weight, bias, layout, dtype, act=None):
-    return _Linear.apply(x, weight, bias, layout, act, dtype)
+def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True):
+    """bias_grad=False: the bias is added in forward but its gradient is somebody else's job (add_layer_norm(delta_bias=))."""
+    return _Linear.apply(x, weight, bias, layout, act, dtype, bias_grad)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -423,7 +423,7 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
-    def fused_forward(self, x, delta, dtype, lp):
+    def fused_forward(self, x, delta, delta_bias, dtype, lp):
         """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
         block's MLP output, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel."""
         at = self.attn
@@ -431,13 +431,15 @@ class NonResidualGPT2Block(nn.Module):
         if delta is None:
             x1, h1 = x, fused.layer_norm(x, self.ln_1, dtype)
         else:
-            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype)
+            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias)
         qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
         a, present = fused.packed_attention(qkv, lp, at._scale())
-        a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype)
-        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype)
+        # the two projections that feed a residual add leave their bias gradient to the LayerNorm backward that follows
+        a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
+        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias)
         g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh")
-        return x2, fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), present
+        delta = fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype, bias_grad=False)
+        return x2, delta, self.mlp.c_proj.bias, present
 
 
 class NonResidualGPT2Model(_LMBase):
@@ -479,11 +481,12 @@ class NonResidualGPT2LMHeadModel(_LMBase):
             dtype = fused.compute_dtype(tr.wte.weight)
             fused.prepare_weights(self, dtype)
             with torch.autocast("cuda", enabled=False):
-                x, delta, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, []
+                x, delta, delta_bias, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, None, []
                 for i, block in enumerate(tr.h):
-                    x, delta, present = block.fused_forward(x, delta, dtype, _layer_past(textualPast, i) if branch else None)
+                    x, delta, delta_bias, present = block.fused_forward(x, delta, delta_bias, dtype,
+                                                                        _layer_past(textualPast, i) if branch else None)
                     presents.append(present)
-                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype)
+                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias)
                 head = self.lm_head if returnLmLogits else self.valueHead
                 logits = fused.linear(y, head.weight, None, "oi", dtype)
             return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,

@@ -122,24 +122,25 @@ struct LnBwdArgs {
   const float* dres;
   float* dx;
   void* dx_lp;
-  float* partial;   // [gridDim.x][2][C]
+  float* partial;   // [gridDim.x][2 or 3][C]
   int64_t rows;
   int C;
 };
 
-// TY: dtype of dy;  TL: dtype of the low-precision copy of dx (ignored when dx_lp == nullptr)
-template <typename TY, typename TL, int NV>
+// TY: dtype of dy;  TL: dtype of the low-precision copy of dx (ignored when dx_lp == nullptr);  COLSUM: also the column sums
+// of dx as the preceding projection sees it (rounded to TL when dx_lp is given) - that projection's bias gradient
+template <typename TY, typename TL, int NV, bool COLSUM>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
-  extern __shared__ float lds[];   // [2][C]
+  extern __shared__ float lds[];   // [2 or 3][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C;
   const float inv_c = 1.0f / (float)C;
-  float gam[NV][4], dg[NV][4], db[NV][4];
+  float gam[NV][4], dg[NV][4], db[NV][4], ds[COLSUM ? NV : 1][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * (lane + 64 * i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gam[i][j] = dg[i][j] = db[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) gam[i][j] = dg[i][j] = db[i][j] = ds[COLSUM ? i : 0][j] = 0.f;
     if (c < C) load4<float>(a.gamma + c, gam[i]);
   }
   for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < a.rows; r += (int64_t)gridDim.x * 4) {
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
         }
         store4<float>(a.dx + r * C + c, o);
         if (a.dx_lp) store4<TL>((TL*)a.dx_lp + r * C + c, o);
+        if constexpr (COLSUM) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ds[i][j] += a.dx_lp ? to_f32(from_f32<TL>(o[j])) : o[j];
+        }
       }
     }
   }
@@ -200,9 +205,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
             if (w == 0) {
               lds[c + j] = dg[i][j];
               lds[C + c + j] = db[i][j];
+              if constexpr (COLSUM) lds[2 * C + c + j] = ds[i][j];
             } else {
               lds[c + j] += dg[i][j];
               lds[C + c + j] += db[i][j];
+              if constexpr (COLSUM) lds[2 * C + c + j] += ds[i][j];
             }
           }
         }
@@ -210,17 +217,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
     }
     __syncthreads();
   }
-  float* part = a.partial + (int64_t)blockIdx.x * 2 * C;
-  for (int c = threadIdx.x; c < 2 * C; c += 256) part[c] = lds[c];
+  constexpr int NP = COLSUM ? 3 : 2;
+  float* part = a.partial + (int64_t)blockIdx.x * NP * C;
+  for (int c = threadIdx.x; c < NP * C; c += 256) part[c] = lds[c];
 }
 
-// out0[c] += sum_g partial[g][c] (c < n0), out1[c - n0] += ... (n0 <= c < n0 + n1).  256 threads = 32 columns x 8 slices of
-// g; every thread adds its slice in increasing g, then the 8 slice sums are added in slice order: a fixed summation order.
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int G, int n0, int n1, float* out0, float* out1) {
+// out0[c] += sum_g partial[g][c] (c < n0), out1[c - n0] += ... (n0 <= c < n0 + n1), out2 likewise.  256 threads = 32 columns
+// x 8 slices of g; every thread adds its slice in increasing g, then the 8 slice sums are added in slice order: a fixed
+// summation order.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int G, int n0, int n1, int n2, float* out0, float* out1,
+                                                             float* out2) {
   __shared__ float red[8][33];
   const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + col;
-  const int n = n0 + n1;
+  const int n = n0 + n1 + n2;
   float s = 0.f;
   if (c < n) {
 #pragma unroll 8
@@ -233,7 +243,8 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partia
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += red[k][col];
     if (c < n0) out0[c] += t;
-    else out1[c - n0] += t;
+    else if (c < n0 + n1) out1[c - n0] += t;
+    else out2[c - n0 - n1] += t;
   }
 }
 
@@ -307,15 +318,20 @@ static void launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 16>), grid, block, 0, st, a);
 }
 
-template <typename TY, typename TL>
-static void launch_ln_bwd(const LnBwdArgs& a, int G, hipStream_t st) {
+template <typename TY, typename TL, bool COLSUM>
+static void launch_ln_bwd2(const LnBwdArgs& a, int G, hipStream_t st) {
   dim3 grid((unsigned)G), block(256);
-  const size_t lds = (size_t)2 * a.C * sizeof(float);
+  const size_t lds = (size_t)(COLSUM ? 3 : 2) * a.C * sizeof(float);
   const int nv = (int)cdiv(a.C, 256);
-  if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2>), grid, block, lds, st, a);
-  else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4>), grid, block, lds, st, a);
-  else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 8>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 16>), grid, block, lds, st, a);
+  if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2, COLSUM>), grid, block, lds, st, a);
+  else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4, COLSUM>), grid, block, lds, st, a);
+  else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 8, COLSUM>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 16, COLSUM>), grid, block, lds, st, a);
+}
+template <typename TY, typename TL>
+static void launch_ln_bwd(const LnBwdArgs& a, int G, bool colsum, hipStream_t st) {
+  if (colsum) launch_ln_bwd2<TY, TL, true>(a, G, st);
+  else launch_ln_bwd2<TY, TL, false>(a, G, st);
 }
 
 }  // namespace bg
@@ -351,12 +367,12 @@ extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, int delta
 
 extern "C" size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
-  return (size_t)ln_groups(rows) * 2 * (size_t)C * sizeof(float);
+  return (size_t)ln_groups(rows) * 3 * (size_t)C * sizeof(float);
 }
 
 extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
-                                float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* dbeta, float* dx_colsum, void* workspace, size_t workspace_bytes, void* stream) {
   BG_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "bg_layernorm_bwd: null argument");
   BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_layernorm_bwd: rows=%lld", (long long)rows);
   BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_layernorm_bwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
@@ -369,18 +385,20 @@ extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     return BG_ERR_WORKSPACE;
   }
   const int G = ln_groups(rows);
+  const bool colsum = dx_colsum != nullptr;
   LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, dx_lp, (float*)workspace, rows, C};
   hipStream_t st = (hipStream_t)stream;
   const bool lbf = dx_lp && lp_dtype == BG_BF16;
   if (dy_dtype == BG_BF16) {
-    if (lbf) launch_ln_bwd<bf16_t, bf16_t>(a, G, st);
-    else launch_ln_bwd<bf16_t, float>(a, G, st);
+    if (lbf) launch_ln_bwd<bf16_t, bf16_t>(a, G, colsum, st);
+    else launch_ln_bwd<bf16_t, float>(a, G, colsum, st);
   } else {
-    if (lbf) launch_ln_bwd<float, bf16_t>(a, G, st);
-    else launch_ln_bwd<float, float>(a, G, st);
+    if (lbf) launch_ln_bwd<float, bf16_t>(a, G, colsum, st);
+    else launch_ln_bwd<float, float>(a, G, colsum, st);
   }
   BG_CHECK_LAUNCH("bg_layernorm_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, C, dgamma, dbeta);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv((colsum ? 3 : 2) * C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, C,
+                     colsum ? C : 0, dgamma, dbeta, dx_colsum);
   BG_CHECK_LAUNCH("bg_layernorm_bwd(reduce)");
   return BG_OK;
 }
@@ -419,7 +437,8 @@ extern "C" int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, i
   else BG_LAUNCH_BA(bf16_t);
 #undef BG_LAUNCH_BA
   BG_CHECK_LAUNCH("bg_bias_act_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, 0, dbias, (float*)nullptr);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, 0, 0, dbias, (float*)nullptr,
+                     (float*)nullptr);
   BG_CHECK_LAUNCH("bg_bias_act_bwd(reduce)");
   return BG_OK;
 }

@@ -167,7 +167,9 @@ int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dty
  *   y = (xn - mean) * rstd * gamma + beta, mean / rstd per row (biased variance, eps inside the root).
  *   x, x_out fp32 [rows][C]; delta [rows][C] of delta_dtype; y [rows][C] of y_dtype; mean, rstd fp32 [rows].
  * bg_layernorm_bwd:  dx = dres + LayerNorm'(dy) (dres may be NULL); dx_lp (optional) = dx rounded to lp_dtype
- *   (the gradient the preceding projection's GEMMs consume);  dgamma += sum_r dy * xhat;  dbeta += sum_r dy.
+ *   (the gradient the preceding projection's GEMMs consume);  dgamma += sum_r dy * xhat;  dbeta += sum_r dy;
+ *   dx_colsum (optional, fp32 [C]) += sum_r dx as that projection sees it (the rounded dx_lp when given): its bias
+ *   gradient, so the projection needs no column-sum pass of its own.
  * bg_bias_act_bwd:  act 0: dbias += column sums of dy [rows][C] (row stride dy_row_stride);
  *   act 1 / 2: dx = dy * gelu'(pre) (tanh / erf form), dbias += column sums of dx.
  * C % 4 == 0; LayerNorm: C <= 4096.  The column reductions are deterministic (per-workgroup partials in the
@@ -179,7 +181,7 @@ int bg_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, int
 size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* dres, int64_t rows, int C,
-                     float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta,
+                     float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta, float* dx_colsum,
                      void* workspace, size_t workspace_bytes, void* stream);
 size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C);
 int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride,

@@ -160,3 +160,37 @@ def test_fused_gpt2_bf16_autocast_close_to_modules():
     for n in ref_grad:      # two bf16 computations of the same gradient: compare by relative Frobenius error
         err = (got_grad[n] - ref_grad[n]).norm() / (ref_grad[n].norm() + 1e-12)
         assert err < 5e-2, (n, float(err))
+
+
+@pytest.mark.parametrize("rows,C", [(5, 64), (300, 768), (3072, 768), (1024, 1600)])
+@pytest.mark.parametrize("lowp", [False, True])
+@pytest.mark.parametrize("use_y", [True, False])
+def test_projection_bias_gradient_from_layernorm_backward(rows, C, lowp, use_y):
+    """linear(bias_grad=False) -> add_layer_norm(delta_bias=bias): the bias gradient comes out of the LayerNorm backward kernel
+    (column sums of the rounded delta gradient) and equals what the projection's own column-sum pass accumulates - the same
+    fp32 sums of the same values in another fixed order: rtol 1e-5, atol 1e-5 * sqrt(rows)."""
+    from branchgan import fused
+    fused.ACCUMULATE_IN_PLACE = True
+    torch.manual_seed(rows + C)
+    dt = torch.bfloat16 if lowp else torch.float32
+    n_in = 96
+    x = torch.randn(rows, C, device="cuda")
+    h = (0.5 * torch.randn(rows, n_in, device="cuda")).to(dt)
+    ln = torch.nn.LayerNorm(C).cuda()
+    gx, gy = torch.randn(rows, C, device="cuda"), torch.randn(rows, C, device="cuda").to(dt)
+    grads = []
+    for split in (False, True):
+        w = torch.nn.Parameter(0.1 * torch.randn(n_in, C, device="cuda", generator=torch.Generator("cuda").manual_seed(1)))
+        b = torch.nn.Parameter(0.1 * torch.randn(C, device="cuda", generator=torch.Generator("cuda").manual_seed(2)))
+        b.grad = torch.full_like(b, 0.125)              # accumulates
+        ln.weight.grad = ln.bias.grad = None
+        delta = fused.linear(h, w, b, "io", dt, bias_grad=not split)
+        x_new, y = fused.add_layer_norm(x, delta, ln, dt, b if split else None)
+        if use_y:
+            torch.autograd.backward([x_new, y], [gx, gy])
+        else:
+            x_new.backward(gx)                          # only the residual output used: the fallback branch
+        grads.append((b.grad.clone(), w.grad.clone()))
+    torch.testing.assert_close(grads[1][0], grads[0][0], rtol=1e-5, atol=1e-5 * rows ** 0.5)
+    assert torch.equal(grads[1][1], grads[0][1])
+    assert float((grads[0][0] - 0.125).abs().max()) > 0.1
