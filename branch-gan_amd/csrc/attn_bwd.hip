@@ -65,12 +65,22 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
+  // software pipeline as in the forward: the global loads of tile i+1 are in flight while tile i is consumed
+  TileRegs<T, DH, 256> kreg, vreg;
+  if (block_ctx > 0) {
+    kreg.load(kt, sh.t_ss, 0, sh.S_text, tid);
+    vreg.load(vt, sh.t_ss, 0, sh.S_text, tid);
+  }
   for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
+    __syncthreads();  // previous tile fully consumed
+    if constexpr (sizeof(T) == 4) kreg.template store<true, false>(k_row, nullptr, tid);
+    else kreg.template store<true, true>(k_row, k_col, tid);
+    vreg.template store<true, false>(v_row, nullptr, tid);
     __syncthreads();
-    if constexpr (sizeof(T) == 4) stage_tile<T, DH, true, false>(kt, sh.t_ss, kb, sh.S_text, k_row, nullptr, tid, 256);
-    else stage_tile<T, DH, true, true>(kt, sh.t_ss, kb, sh.S_text, k_row, k_col, tid, 256);
-    stage_tile<T, DH, true, false>(vt, sh.t_ss, kb, sh.S_text, v_row, nullptr, tid, 256);
-    __syncthreads();
+    if (kb + ATT_TILE < block_ctx) {
+      kreg.load(kt, sh.t_ss, kb + ATT_TILE, sh.S_text, tid);
+      vreg.load(vt, sh.t_ss, kb + ATT_TILE, sh.S_text, tid);
+    }
     if (kb >= wave_ctx) continue;
 
     f32x16 s, dp;
@@ -148,61 +158,99 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  for (int q0 = 0; q0 < R; q0 += ATT_TILE) {
-    // queries of this tile, their ctx: skip the tile if none of them reaches this workgroup's keys
+  // Query tiles that reach this workgroup's keys, with the gather of tile i+1 (Q, dO rows at arbitrary strides: 16-byte chunks,
+  // plus lse / delta / ctx of its queries) in flight while tile i is consumed.
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int CPR = DH / VEC;                          // 16-byte chunks per row
+  constexpr int PER = (ATT_TILE * CPR + 255) / 256;      // chunks per thread
+  typedef typename TileRegs<T, DH, 256>::V Chunk;
+  Chunk q_reg[PER], do_reg[PER];
+  float lse_reg = 0.f, delta_reg = 0.f;
+  int ctx_reg = 0;
+  // max ctx over the queries of tile q0 (uniform over the workgroup); also leaves this lane's query in (n, kq, ctx)
+  auto tile_reach = [&](int q0, int& n, int& kq, int& ctx) {
     const int rq = q0 + (lane & 31);
     const bool qv = rq < R;
-    const int n = qv ? rq / sh.K : 0, kq = qv ? rq % sh.K : 0;
-    const int ctx = qv ? min(a.ctx_len[kq], sh.S_text) : 0;
-    int tile_ctx = ctx;
+    n = qv ? rq / sh.K : 0;
+    kq = qv ? rq % sh.K : 0;
+    ctx = qv ? min(a.ctx_len[kq], sh.S_text) : 0;
+    int t = ctx;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tile_ctx = max(tile_ctx, __shfl_xor(tile_ctx, o));
-    if (tile_ctx <= key0_block) continue;  // uniform over the workgroup
-
-    __syncthreads();
-    // stage Q and dO rows of the tile: row i of the tile = query q0 + i (rows live at arbitrary strides,
-    // so gather them one query at a time: 8 threads per query row)
-    {
-      constexpr int VEC = 16 / sizeof(T);
-      constexpr int CPR = DH / VEC;  // 16-byte chunks per row
-      for (int c = tid; c < ATT_TILE * CPR; c += 256) {
-        const int r = c / CPR, d0 = (c % CPR) * VEC;
-        const int rr = q0 + r;
-        const bool ok = rr < R;
-        const int nn = ok ? rr / sh.K : 0, kk = ok ? rr % sh.K : 0;
-        const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)nn * sh.q_sn + (int64_t)kk * sh.q_sk + d0;
-        const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)nn * sh.o_sn + (int64_t)kk * sh.o_sk + d0;
-        if constexpr (sizeof(T) == 4) {
-          f32x4 qv4 = {0.f, 0.f, 0.f, 0.f}, dv4 = {0.f, 0.f, 0.f, 0.f};
-          if (ok) { qv4 = *(const f32x4*)((const T*)a.q + qoff); dv4 = *(const f32x4*)((const T*)a.dout + ooff); }
+    for (int o = 32; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
+    return t;
+  };
+  auto next_tile = [&](int q0, int& reach) {             // first tile at or after q0 that reaches the keys, or >= R
+    int n, kq, ctx;
+    for (; q0 < R; q0 += ATT_TILE) {
+      reach = tile_reach(q0, n, kq, ctx);
+      if (reach > key0_block) break;
+    }
+    return q0;
+  };
+  auto gather = [&](int q0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            q_row_l[r * L::RSTRIDE + d0 + j] = qv4[j];
-            do_row_l[r * L::RSTRIDE + d0 + j] = dv4[j];
-          }
-        } else {
-          bf16x8 qv8, dv8;
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * 256;
+      const int r = c / CPR, d0 = (c % CPR) * VEC;
+      const int rr = q0 + r;
+      const bool ok = c < ATT_TILE * CPR && rr < R;
+      const int nn = ok ? rr / sh.K : 0, kk = ok ? rr % sh.K : 0;
+      const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)nn * sh.q_sn + (int64_t)kk * sh.q_sk + d0;
+      const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)nn * sh.o_sn + (int64_t)kk * sh.o_sk + d0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { qv8[j] = (bf16_t)0.0f; dv8[j] = (bf16_t)0.0f; }
-          if (ok) { qv8 = *(const bf16x8*)((const T*)a.q + qoff); dv8 = *(const bf16x8*)((const T*)a.dout + ooff); }
-          *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = qv8;
-          *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = dv8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            q_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = qv8[j];
-            do_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = dv8[j];
-          }
-        }
-      }
-      if (tid < ATT_TILE) {
-        const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
-        lse_s[tid] = qv ? a.lse[stat] : 0.f;
-        delta_s[tid] = qv ? a.delta[stat] : 0.f;
-        ctx_s[tid] = ctx;  // 0 for invalid queries: masks everything
+      for (int j = 0; j < VEC; ++j) { q_reg[i][j] = (T)0.0f; do_reg[i][j] = (T)0.0f; }
+      if (ok) {
+        q_reg[i] = *(const Chunk*)((const T*)a.q + qoff);
+        do_reg[i] = *(const Chunk*)((const T*)a.dout + ooff);
       }
     }
+    if (tid < ATT_TILE) {
+      int n, kq;
+      tile_reach(q0, n, kq, ctx_reg);                    // wave 0 only: its own shuffle, same values
+      const bool qv = q0 + tid < R;
+      const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
+      lse_reg = qv ? a.lse[stat] : 0.f;
+      delta_reg = qv ? a.delta[stat] : 0.f;
+    }
+  };
+  int tile_ctx = 0, next_ctx = 0;
+  int q0 = next_tile(0, tile_ctx);
+  if (q0 < R) gather(q0);
+  while (q0 < R) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * 256;
+      if (c >= ATT_TILE * CPR) continue;
+      const int r = c / CPR, d0 = (c % CPR) * VEC;
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          q_row_l[r * L::RSTRIDE + d0 + j] = q_reg[i][j];
+          do_row_l[r * L::RSTRIDE + d0 + j] = do_reg[i][j];
+        }
+      } else {
+        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = q_reg[i];
+        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = do_reg[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          q_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = q_reg[i][j];
+          do_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = do_reg[i][j];
+        }
+      }
+    }
+    if (tid < ATT_TILE) {
+      lse_s[tid] = lse_reg;
+      delta_s[tid] = delta_reg;
+      ctx_s[tid] = ctx_reg;  // 0 for invalid queries: masks everything
+    }
     __syncthreads();
-    if (tile_ctx <= key0_wave) continue;  // wave-uniform: nothing in this tile sees this wave's keys
+    const int q1 = next_tile(q0 + ATT_TILE, next_ctx);
+    if (q1 < R) gather(q1);
+    const int this_ctx = tile_ctx;
+    q0 = q1;
+    tile_ctx = next_ctx;
+    if (this_ctx <= key0_wave) continue;  // wave-uniform: nothing in this tile sees this wave's keys
 
     f32x16 s, dp;
 #pragma unroll
