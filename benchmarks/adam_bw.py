@@ -25,4 +25,6 @@ def run(n=124_439_808, reps=20):
 
 
 if __name__ == "__main__":
-    run()
+    # `python benchmarks/adam_bw.py [n]`; under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` for the traffic passes
+    for size in (sys.argv[1:] or ["124439808"]):
+        run(int(size))

@@ -6,9 +6,9 @@ import sys
 
 
 def klass(n):
-    if n.startswith('Cijk') or 'gemm' in n.lower(): return 'gemm (hipBLASLt)'
-    if '_ZN2bg' in n:
-        for k in ('attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_slots', 'attn_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'bias_act_bwd',
+    if n.startswith('Cijk') or n.startswith('Custom_Cijk') or 'gemm' in n.lower(): return 'gemm (hipBLASLt)'
+    if '_ZN2bg' in n or 'bg::' in n:
+        for k in ('adam_step', 'embed_', 'attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_slots', 'attn_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'bias_act_bwd',
                   'partial_reduce', 'softmax_stats', 'topn', 'topp', 'loss', 'rope'):
             if k in n: return 'bg:' + k
         return 'bg:other'

@@ -33,6 +33,7 @@ class ArenaAdam(torch.optim.Optimizer):
         self.grad_arena = None      # branchgan.training.GradArena, set by bind()
         self.param_arena = self.exp_avg = self.exp_avg_sq = self.lowp_arena = None
         self._outside = []
+        self.timing = None          # a list: step() appends (start, end) HIP events recorded around its launch (bench.py)
 
     def bind(self, grad_arena):
         """OptimizerWrapper hands over the model's GradArena: this optimizer steps exactly the parameters whose gradients
@@ -89,10 +90,16 @@ class ArenaAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.steps += 1
         lp = self.lowp_arena
+        if self.timing is not None:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
         C.check(C.lib().bg_adam_step(C.ptr(self.param_arena), C.ptr(self.grad_arena.arena), C.ptr(self.exp_avg), C.ptr(self.exp_avg_sq),
                                      C.ptr(lp), C.dtype_code(lp) if lp is not None else 0, self.param_arena.numel(),
                                      float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                      float(g['weight_decay']), self.steps, float(self.grad_scale), 1, C.stream_ptr()), "bg_adam_step")
+        if self.timing is not None:
+            t1.record()
+            self.timing.append((t0, t1))
         return loss
 
     def zero_grad(self, set_to_none=False):
