@@ -38,31 +38,40 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_fwd_kernel(const int64_t*
 }
 
 // first[r] = min { j <= r : idx[j] == idx[r] } within the chunk [0, n); a row whose index is outside the table matches nothing.
-// Every lane of a wave reads the same LDS words (broadcast), four indices per read.
+// One workgroup per 64 rows (row on the lane); its four waves scan a quarter of [0, r] each - every lane of a wave reads the
+// same LDS words (broadcast), four indices per read - and the quarters' minima are combined through LDS.
+#define EMBED_FIRST_ROWS 64
 __global__ __launch_bounds__(EMBED_THREADS) void embed_first_kernel(const int64_t* __restrict__ idx, int64_t base, int64_t idx_rows, int n,
                                                                      int64_t table_rows, int* __restrict__ first) {
   __shared__ __align__(16) int s_idx[EMBED_CHUNK];
-  for (int j = threadIdx.x; j < ((n + 3) & ~3); j += EMBED_THREADS) {
+  __shared__ int s_min[4][EMBED_FIRST_ROWS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * EMBED_FIRST_ROWS;
+  const int r_last = min(n - 1, r0 + EMBED_FIRST_ROWS - 1);          // only indices up to the last row of this workgroup matter
+  for (int j = threadIdx.x; j < ((r_last + 4) & ~3); j += EMBED_THREADS) {
     int key = -1;
-    if (j < n) {
+    if (j <= r_last) {
       const int64_t t = idx[(base + j) % idx_rows];
       key = (t >= 0 && t < table_rows) ? (int)t : -(j + 3);
     }
     s_idx[j] = key;
   }
   __syncthreads();
-  const int r = blockIdx.x * EMBED_THREADS + threadIdx.x;
+  const int r = r0 + lane;
   const int mine = r < n ? s_idx[r] : -2;
-  const int wave_last = min(n - 1, (r | 63));          // the highest row of this wave: the scan bound is wave-uniform
+  const int quarter = (((r_last + 4) >> 2) + 3) >> 2 << 2;            // int4 reads per wave, rounded up: 4 quarters cover [0, r_last]
+  const int j_begin = wave * quarter, j_end = min(j_begin + quarter, (r_last + 4) & ~3);
   int f = r;
-  for (int j = 0; j <= wave_last; j += 4) {
+  for (int j = j_begin; j < j_end; j += 4) {
     const int4 v = *(const int4*)&s_idx[j];
     if (v.w == mine && j + 3 < f) f = j + 3;
     if (v.z == mine && j + 2 < f) f = j + 2;
     if (v.y == mine && j + 1 < f) f = j + 1;
     if (v.x == mine && j < f) f = j;
   }
-  if (r < n) first[r] = f;
+  s_min[wave][lane] = f;
+  __syncthreads();
+  if (wave == 0 && r < n) first[r] = min(min(s_min[0][lane], s_min[1][lane]), min(s_min[2][lane], s_min[3][lane]));
 }
 
 #define EMBED_U 16            // rows in flight per wave
@@ -89,6 +98,17 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_accum_kernel(const float*
     const int j = j_begin + k * EMBED_THREADS + threadIdx.x;
     if (j >= r && j < n && first[j] == r) hits |= 1u << k;
   }
+  const int c = 256 * blockIdx.y + 4 * lane;
+  const bool live = c < C;
+  const float* src = dy + base * (int64_t)C + c;
+  // most indices occur once (the tail of a token distribution): nothing to gather
+  if (__syncthreads_count(hits != 0) == 1 && __syncthreads_count(__popc(hits) > 1) == 0) {
+    if (wave == 0 && live) {
+      f32x4* dst = (f32x4*)(dW + t * C + c);
+      *dst += __builtin_nontemporal_load((const f32x4*)(src + (int64_t)r * C));
+    }
+    return;
+  }
   // ordered compaction into s_list
   if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
@@ -106,9 +126,6 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_accum_kernel(const float*
   }
   const int total = s_total;
   // wave w sums list entries w, w + 4, ... in ascending order; its lanes span 256 columns
-  const int c = 256 * blockIdx.y + 4 * lane;
-  const bool live = c < C;
-  const float* src = dy + base * (int64_t)C + c;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int e = wave; e < total; e += 4 * EMBED_U) {
     f32x4 x[EMBED_U];
@@ -161,7 +178,7 @@ extern "C" int bg_embed_bwd(const float* dy, const int64_t* idx, int64_t rows, i
   int* first = (int*)workspace;
   for (int64_t base = 0; base < rows; base += EMBED_CHUNK) {       // chunks run back to back on the stream: dW accumulates
     const int n = (int)(rows - base < EMBED_CHUNK ? rows - base : EMBED_CHUNK);
-    hipLaunchKernelGGL(embed_first_kernel, dim3((unsigned)cdiv(n, EMBED_THREADS)), dim3(EMBED_THREADS), 0, st, idx, base, idx_rows, n, table_rows,
+    hipLaunchKernelGGL(embed_first_kernel, dim3((unsigned)cdiv(n, EMBED_FIRST_ROWS)), dim3(EMBED_THREADS), 0, st, idx, base, idx_rows, n, table_rows,
                        first);
     BG_CHECK_LAUNCH("bg_embed_bwd(first)");
     hipLaunchKernelGGL(embed_accum_kernel, dim3((unsigned)n, (unsigned)cdiv(C, 256)), dim3(EMBED_THREADS), 0, st, dy, idx, base, idx_rows, first, n, C,
