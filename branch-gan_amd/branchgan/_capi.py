@@ -53,7 +53,7 @@ SIGNATURES = {
     "bg_branch_attn_fwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_branch_attn_bwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
-                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                   c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                    ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_vp]),
     "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),

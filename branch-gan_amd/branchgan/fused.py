@@ -415,7 +415,7 @@ def _attn_fwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse)
                                            C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
 
 
-def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv):
+def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv, dkt_in=None, dvt_in=None):
     path, path_len, max_path = ops.path_tables(paths, q5.device)
     sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
     sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
@@ -423,8 +423,8 @@ def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse,
     with ops._timed("branch_attn_bwd"):
         C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
                                            ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                           C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), ops._ptr_array(dsk),
-                                           ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+                                           C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), C.ptr(dkt_in), C.ptr(dvt_in),
+                                           ops._ptr_array(dsk), ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
 
 
 def _heads_first(t, NQ, K):
@@ -463,7 +463,7 @@ class _MergedTreeAttention(torch.autograd.Function):
         qkv, att, lse_r, lse_t, ctx_len = ctx.saved_tensors
         S, N, K, scale, paths = ctx.meta
         B, T, _, H, Dh = qkv.shape
-        dqkv, dtmp = torch.empty_like(qkv), torch.empty_like(qkv)    # dtmp: the tree rows' contribution to the text keys / values
+        dqkv = torch.empty_like(qkv)
         if datt is None:
             datt = torch.zeros((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
         do = datt.reshape(B, T, H, Dh).to(qkv.dtype).contiguous()
@@ -476,8 +476,8 @@ class _MergedTreeAttention(torch.autograd.Function):
         own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
         _attn_bwd_call(_heads_first(qkv[:, S:, 0], N, K), kt, vt, own(kview), own(vview), ctx_len, paths, scale,
                        _heads_first(att[:, S:], N, K), lse_t, _heads_first(do[:, S:], N, K), _heads_first(dqkv[:, S:, 0], N, K),
-                       dtmp[:, :, 1].permute(0, 2, 1, 3)[:, :, :S], dtmp[:, :, 2].permute(0, 2, 1, 3)[:, :, :S], own(dkview), own(dvview))
-        dqkv[:, :S, 1:].add_(dtmp[:, :S, 1:])
+                       dkview[:, :, :S], dvview[:, :, :S], own(dkview), own(dvview),
+                       dkt_in=dkview[:, :, :S], dvt_in=dvview[:, :, :S])     # the tree rows' share of the text dK / dV: added in the kernel
         if dk_out is not None:
             dkview.add_(dk_out)
         if dv_out is not None:
@@ -553,10 +553,16 @@ class _PackedAttention(torch.autograd.Function):
             do5 = do5.contiguous()
         do5 = do5.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
         d_anc_k, d_anc_v = [], []
+        dk_in = dv_in = None
         if root:
             kt, vt = kview, vview
             dkt, dvt = dkview, dvview
             slots_k, slots_v, dsk, dsv = [], [], [], []
+            # what the tree pass sent back to the text keys / values: same layout -> added inside the dkv kernel
+            if dk_out is not None and dv_out is not None and dk_out.dtype == dt and dv_out.dtype == dt \
+                    and dk_out.stride() == dkt.stride() and dv_out.stride() == dvt.stride() \
+                    and dk_out.data_ptr() % 16 == 0 and dv_out.data_ptr() % 16 == 0:
+                dk_in, dv_in, dk_out, dv_out = dk_out, dv_out, None, None
         else:
             kt, vt = rest[0], rest[1]
             anc_k, anc_v = rest[2:2 + n_anc], rest[2 + n_anc:]
@@ -580,8 +586,8 @@ class _PackedAttention(torch.autograd.Function):
         with ops._timed("branch_attn_bwd"):
             C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
                                                ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                               C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), ops._ptr_array(dsk),
-                                               ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+                                               C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), C.ptr(dk_in), C.ptr(dv_in),
+                                               ops._ptr_array(dsk), ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
         if dk_out is not None:      # what the descendants' attention sent back to this node's keys / values
             dkview.add_(dk_out)
         if dv_out is not None:

@@ -246,7 +246,7 @@ class _BranchAttention(torch.autograd.Function):
         with _timed("branch_attn_bwd"):
             C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
                                                _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
-                                               C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text),
+                                               C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text), None, None,
                                                _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
                     "bg_branch_attn_bwd")
         return (dq, dk_text, dv_text, None, None, None, None, None, None, *dks, *dvs)

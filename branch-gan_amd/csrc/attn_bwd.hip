@@ -270,23 +270,33 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
   }
 
   if (kvalid) {
-    T* dk_row = (T*)a.dk_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
-    T* dv_row = (T*)a.dv_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+    const int64_t row_off = (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
+    T* dk_row = (T*)a.dk_text + row_off;
+    T* dv_row = (T*)a.dv_text + row_off;
+    // gradients other consumers of these keys / values already produced (same layout; may be the output rows themselves):
+    // added in fp32 before the one rounding, instead of a separate add kernel over the stored result
+    const T* dk_in = a.dk_text_in ? (const T*)a.dk_text_in + row_off : nullptr;
+    const T* dv_in = a.dv_text_in ? (const T*)a.dv_text_in + row_off : nullptr;
 #pragma unroll
     for (int dt = DT0; dt < DT1; ++dt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = dt * 32 + 8 * g + 4 * h;
+        float ik[4] = {0.f, 0.f, 0.f, 0.f}, iv[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (sizeof(T) == 4) {
+          if (dk_in) { const f32x4 t = *(const f32x4*)(dk_in + d); for (int j = 0; j < 4; ++j) ik[j] = t[j]; }
+          if (dv_in) { const f32x4 t = *(const f32x4*)(dv_in + d); for (int j = 0; j < 4; ++j) iv[j] = t[j]; }
           f32x4 ok, ov;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { ok[j] = dk[dt][4 * g + j]; ov[j] = dv[dt][4 * g + j]; }
+          for (int j = 0; j < 4; ++j) { ok[j] = dk[dt][4 * g + j] + ik[j]; ov[j] = dv[dt][4 * g + j] + iv[j]; }
           *(f32x4*)(dk_row + d) = ok;
           *(f32x4*)(dv_row + d) = ov;
         } else {
+          if (dk_in) { const bf16x4 t = *(const bf16x4*)(dk_in + d); for (int j = 0; j < 4; ++j) ik[j] = (float)t[j]; }
+          if (dv_in) { const bf16x4 t = *(const bf16x4*)(dv_in + d); for (int j = 0; j < 4; ++j) iv[j] = (float)t[j]; }
           bf16x4 ok, ov;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { ok[j] = (bf16_t)dk[dt][4 * g + j]; ov[j] = (bf16_t)dv[dt][4 * g + j]; }
+          for (int j = 0; j < 4; ++j) { ok[j] = (bf16_t)(dk[dt][4 * g + j] + ik[j]); ov[j] = (bf16_t)(dv[dt][4 * g + j] + iv[j]); }
           *(bf16x4*)(dk_row + d) = ok;
           *(bf16x4*)(dv_row + d) = ov;
         }
@@ -405,8 +415,9 @@ using namespace bg;
 extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, const void* k_text, const void* v_text,
                                   const void* const* k_slots, const void* const* v_slots, const int32_t* ctx_len,
                                   const int32_t* path, const int32_t* path_len, const void* out, const float* lse,
-                                  const void* dout, void* dq, void* dk_text, void* dv_text, void* const* dk_slots,
-                                  void* const* dv_slots, float* delta, void* stream) {
+                                  const void* dout, void* dq, void* dk_text, void* dv_text, const void* dk_text_in,
+                                  const void* dv_text_in, void* const* dk_slots, void* const* dv_slots, float* delta,
+                                  void* stream) {
   const char* who = "bg_branch_attn_bwd";
   if (int e = validate_attn_shape(shape, who)) return e;
   if (int e = check_aligned16(q, who, "q")) return e;
@@ -419,6 +430,8 @@ extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, con
     if (int e = check_aligned16(v_text, who, "v_text")) return e;
     if (int e = check_aligned16(dk_text, who, "dk_text")) return e;
     if (int e = check_aligned16(dv_text, who, "dv_text")) return e;
+    if (dk_text_in) if (int e = check_aligned16(dk_text_in, who, "dk_text_in")) return e;
+    if (dv_text_in) if (int e = check_aligned16(dv_text_in, who, "dv_text_in")) return e;
   }
   BG_REQUIRE(shape->max_path == 0 || (path && path_len), "%s: null path/path_len", who);
   AttnArgs a;
@@ -435,6 +448,7 @@ extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, con
   a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
   a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse); a.dout = dout;
   a.dq = dq; a.dk_text = dk_text; a.dv_text = dv_text; a.delta = delta;
+  a.dk_text_in = dk_text_in; a.dv_text_in = dv_text_in;
   for (int i = 0; i < shape->n_slots; ++i) {
     if (int e = check_aligned16(k_slots[i], who, "k_slots[i]")) return e;
     if (int e = check_aligned16(v_slots[i], who, "v_slots[i]")) return e;

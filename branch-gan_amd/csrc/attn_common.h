@@ -37,6 +37,8 @@ struct AttnArgs {
   void* dq;
   void* dk_text;
   void* dv_text;
+  const void* dk_text_in;   // optional: added to dK / dV of the text rows before the store (may alias dk_text / dv_text)
+  const void* dv_text_in;
   void* dk_slots[BG_MAX_SLOTS];
   void* dv_slots[BG_MAX_SLOTS];
   float* delta;

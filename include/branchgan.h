@@ -139,6 +139,10 @@ int bg_branch_attn_bwd(const bg_attn_shape* shape,
                        const int32_t* ctx_len, const int32_t* path, const int32_t* path_len,
                        const void* out, const float* lse, const void* dout,
                        void* dq, void* dk_text, void* dv_text,
+                       const void* dk_text_in, const void* dv_text_in,           /* optional (NULL): gradients of the text keys /
+                                                                                    values from their other consumers, same layout
+                                                                                    as dk_text; dk_text = dK + dk_text_in (added in
+                                                                                    fp32, rounded once); may alias dk_text / dv_text */
                        void* const* dk_slots, void* const* dv_slots,             /* host arrays */
                        float* delta /* fp32 scratch [b][h][n][k] */, void* stream);
 

@@ -194,3 +194,48 @@ def test_projection_bias_gradient_from_layernorm_backward(rows, C, lowp, use_y):
     torch.testing.assert_close(grads[1][0], grads[0][0], rtol=1e-5, atol=1e-5 * rows ** 0.5)
     assert torch.equal(grads[1][1], grads[0][1])
     assert float((grads[0][0] - 0.125).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_backward_adds_incoming_text_gradients(dt):
+    """bg_branch_attn_bwd(dk_text_in, dv_text_in): the text dK / dV other consumers already produced are added inside the dkv
+    kernel (fp32 add, one rounding), also when they live in the output buffer itself.  fp32: equal to the separate add to
+    1e-6; bf16: within one bf16 rounding of it."""
+    from branchgan import fused, ops
+    torch.manual_seed(3)
+    B, H, S, Dh, K, N = 2, 3, 40, 64, 5, 2
+    scale = Dh ** -0.5
+    root = torch.randn(B, S, 3, H, Dh, device="cuda").to(dt)
+    tree = torch.randn(B, N * K, 3, H, Dh, device="cuda").to(dt)
+    kt, vt = root[:, :, 1].permute(0, 2, 1, 3), root[:, :, 2].permute(0, 2, 1, 3)
+    tk, tv = tree[:, :, 1].permute(0, 2, 1, 3), tree[:, :, 2].permute(0, 2, 1, 3)
+    own = lambda t: [t[:, :, n * K:(n + 1) * K] for n in range(N)]
+    ctx = torch.tensor([3, 9, 17, 30, 40], dtype=torch.int32, device="cuda")
+    paths = [[0], [0, 1]]
+    hf = fused._heads_first
+    att = torch.empty(B, N * K, H, Dh, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, N, K, device="cuda")
+    fused._attn_fwd_call(hf(tree[:, :, 0], N, K), kt, vt, own(tk), own(tv), ctx, paths, scale, hf(att, N, K), lse)
+    do = torch.randn_like(att)
+
+    def run(dk_in, dv_in, alias):
+        dtree, dtext = torch.zeros_like(tree), torch.zeros_like(root)
+        dk, dv = dtext[:, :, 1].permute(0, 2, 1, 3), dtext[:, :, 2].permute(0, 2, 1, 3)
+        if alias:
+            dk.copy_(dk_in)
+            dv.copy_(dv_in)
+            dk_in, dv_in = dk, dv
+        dtk, dtv = dtree[:, :, 1].permute(0, 2, 1, 3), dtree[:, :, 2].permute(0, 2, 1, 3)
+        fused._attn_bwd_call(hf(tree[:, :, 0], N, K), kt, vt, own(tk), own(tv), ctx, paths, scale, hf(att, N, K), lse, hf(do, N, K),
+                             hf(dtree[:, :, 0], N, K), dk, dv, own(dtk), own(dtv), dkt_in=dk_in, dvt_in=dv_in)
+        return dk.float().clone(), dv.float().clone(), dtree.float().clone()
+
+    inc = torch.randn(B, S, 3, H, Dh, device="cuda").to(dt)
+    ik, iv = inc[:, :, 1].permute(0, 2, 1, 3), inc[:, :, 2].permute(0, 2, 1, 3)
+    dk0, dv0, dq0 = run(None, None, False)
+    for alias in (False, True):
+        dk1, dv1, dq1 = run(ik, iv, alias)
+        assert torch.equal(dq1, dq0)
+        tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=2 ** -7, atol=2 ** -7)
+        torch.testing.assert_close(dk1, dk0 + ik.float(), **tol)
+        torch.testing.assert_close(dv1, dv0 + iv.float(), **tol)
