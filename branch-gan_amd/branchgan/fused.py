@@ -121,8 +121,12 @@ def prepare_weights(module, dtype):
     capturing = torch.cuda.is_current_stream_capturing()
     pool = (capturing, _capture_epoch if capturing else 0)
     src, dst = [], []
-    for p in module.parameters():
-        if p.dtype != torch.float32 or _pinned_copy(p, dtype) is not None:
+    params = list(module.parameters())
+    if any(_pinned_copy(p, dtype) is not None for p in params):
+        return      # an ArenaAdam keeps this model's copies current; a parameter outside its arenas (an unused head) is cast by
+                    # lowp() if it is ever used - not every step
+    for p in params:
+        if p.dtype != torch.float32:
             continue
         hit = _cast_cache.get(id(p))
         key = _cache_key(p)
@@ -266,15 +270,16 @@ def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None):
 # Token + position embedding
 # ---------------------------------------------------------------------------------------------------------------------
 class _Embedding(torch.autograd.Function):
-    """wte[ids] + wpe[pos] in one launch; backward adds into both tables' fp32 gradients deterministically."""
+    """wte[ids] (+ wpe[pos]) in one launch; backward adds into the tables' fp32 gradients deterministically."""
 
     @staticmethod
     def forward(ctx, ids, pos, wte, wpe):
         rows, C_ = ids.numel(), wte.shape[1]
         out = torch.empty(ids.shape + (C_,), dtype=torch.float32, device=wte.device)
         with ops._timed("embed_fwd"):
-            C.check(C.lib().bg_embed_fwd(C.ptr(ids), rows, C.ptr(pos), pos.numel(), C.ptr(wte.detach()), wte.shape[0],
-                                         C.ptr(wpe.detach()), wpe.shape[0], C_, C.ptr(out), C.stream_ptr()), "bg_embed_fwd")
+            C.check(C.lib().bg_embed_fwd(C.ptr(ids), rows, C.ptr(pos), pos.numel() if pos is not None else 0, C.ptr(wte.detach()),
+                                         wte.shape[0], C.ptr(wpe.detach()) if wpe is not None else None,
+                                         wpe.shape[0] if wpe is not None else 0, C_, C.ptr(out), C.stream_ptr()), "bg_embed_fwd")
         ctx.save_for_backward(ids, pos)
         ctx.params = (wte, wpe)
         return out
@@ -289,7 +294,7 @@ class _Embedding(torch.autograd.Function):
         rets = []
         with ops._timed("embed_bwd"):
             for table, idx in zip(ctx.params, (ids, pos)):
-                if not table.requires_grad:
+                if table is None or not table.requires_grad:
                     rets.append(None)
                     continue
                 buf, ret = _grad_buffer(table)
@@ -299,9 +304,12 @@ class _Embedding(torch.autograd.Function):
         return None, None, rets[0], rets[1]
 
 
-def embedding(input_ids, pos, wte, wpe):
-    """input_ids (B, T) integer; pos (B, T) or (1, T) integer, possibly an expanded view -> fp32 (B, T, C)."""
+def embedding(input_ids, pos, wte, wpe=None):
+    """input_ids (B, T) integer; pos (B, T) or (1, T) integer, possibly an expanded view (None with wpe=None: the token table
+    alone, GPT-NeoX) -> fp32 (B, T, C)."""
     ids = input_ids.contiguous().long()
+    if wpe is None:
+        return _Embedding.apply(ids, None, wte, None)
     if pos.dim() == 2 and pos.shape[0] > 1 and pos.stride(0) == 0:
         pos = pos[0]                                   # one row of positions shared by the batch: rows index it modulo T
     pos = pos.contiguous().long().view(-1)

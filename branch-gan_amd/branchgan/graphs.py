@@ -28,6 +28,23 @@ def _sync_after_replay():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+def _require_fused_path(model, example_ids):
+    """Graph replay is supported for models on the fused block path only.  On the module-by-module path the bias gradients
+    come from ATen's multi-block reductions, and those return NaNs in a few columns from the SECOND replay of a captured
+    graph (measured: GPT-2 small and Pythia-70M at the BASELINE shapes, bf16 autocast, ROCm 7.2 / torch 2.10; the same
+    step is fine eagerly, in fp32, and at the tiny test shapes where the reduction fits one workgroup).  The fused path
+    computes those gradients in this library's kernels.  BRANCHGAN_GRAPH_UNFUSED=1 overrides (debugging)."""
+    if os.environ.get("BRANCHGAN_GRAPH_UNFUSED") == "1":
+        return
+    from . import models
+    for name, lm in (("generator", model.generator.generator), ("discriminator", model.discriminator.nonResidualModel)):
+        if not models._fused_eligible(lm, example_ids, None, None, False):
+            raise NotImplementedError(
+                f"GraphedTrainStep: the {name} does not run on the fused block path (BRANCHGAN_FUSED=0, dropout, a hidden size "
+                "that is not a multiple of 8 or above 4096, a head size outside {32, 64, 128, 256}, non-fp32 parameters): "
+                "use the eager branchgan.training.train_step for it")
+
+
 class GraphedTrainStep:
     def __init__(self, model, sampleConf, generatorOptim, discriminatorOptim, example_ids, numUpdateSamples=9999,
                  reinforcementLearningConfig=None, amp_dtype=None, warmup=3):
@@ -35,6 +52,7 @@ class GraphedTrainStep:
         self.rl, self.n_update, self.amp_dtype = reinforcementLearningConfig, numUpdateSamples, amp_dtype
         self.src_conf = sampleConf
         dev = example_ids.device
+        _require_fused_path(model, example_ids)
         self.static_ids = example_ids.clone()
         K = sampleConf.numSampleSequences or example_ids.shape[1]
         self.static_sparse = torch.zeros(K, dtype=torch.long, device=dev)
@@ -62,13 +80,15 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_d = torch.cuda.CUDAGraph()
         fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
-        with torch.cuda.graph(self.graph_g, capture_error_mode="thread_local"):   # collective backends run helper threads
+        # ONE stream for the warm-up and all three captures: autograd runs every AccumulateGrad node on the stream it was created
+        # on, and a node created while one graph is captured must not end up on another graph's stream
+        with torch.cuda.graph(self.graph_g, stream=side, capture_error_mode="thread_local"):   # collective backends run helper threads
             with self._autocast():
                 self.gen_state = self.model._generatorForward(self.static_ids, self.conf)
-        with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
             self.losses = self._forward(self.gen_state)
             self.losses[1][self.g_opt.lossKey].backward()
-        with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
             self.losses[0][self.d_opt.lossKey].backward()
         ops.TIMING = timing
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated

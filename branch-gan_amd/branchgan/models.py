@@ -184,6 +184,22 @@ class NeoXNonResidualAttention(nn.Module):
         return outputs
 
 
+def _neox_fused_attention(at, h1, pos, dtype, lp):
+    """NeoXNonResidualAttention.forward (:90-148) on the fused path: projections through fused.linear (cached bf16 weights,
+    in-place fp32 dW / bias gradients), split + rotary in one kernel, branch / causal attention kernel."""
+    B, T, _ = h1.shape
+    qkv = fused.linear(h1, at.query_key_value.weight, at.query_key_value.bias, "oi", dtype)
+    cos, sin = rope_tables(at.rotary_ndims, at.config.max_position_embeddings, at.config.rotary_emb_base, qkv.device)
+    query, key, value = ops.neox_qkv_rope(qkv, cos, sin, pos, at.num_attention_heads, at.head_size, at.rotary_ndims)
+    scale = 1.0 / at.norm_factor
+    if lp is not None:
+        out = branch_attention_core(query, key, value, lp, scale)
+    else:
+        out, _ = ops.causal_attention(query, key, value, scale=scale)
+    out = out.permute(0, 2, 1, 3).reshape(B, T, at.hidden_size)
+    return fused.linear(out, at.dense.weight, at.dense.bias, "oi", dtype), (key, value)
+
+
 class GPTNeoXMLP(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -220,6 +236,24 @@ class GPTNeoXLayer(nn.Module):
             hidden_states = drop(self.mlp(self.post_attention_layernorm(attn_output))) + attn_output
         return hidden_states, present
 
+    def fused_forward(self, x, delta, dtype, pos, lp):
+        """Same block on the fused path (see NonResidualGPT2Block.fused_forward).  `x` is the fp32 residual stream BEFORE the
+        previous block's update `delta` (None for the first block); returns (x + delta, this block's update, present).
+        Parallel residual: both LayerNorms read x + delta, the update is attention + MLP."""
+        if delta is None:
+            x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype)
+        else:
+            x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype)
+        a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
+        if self.use_parallel_residual:
+            h2 = fused.layer_norm(x1, self.post_attention_layernorm, dtype)
+            g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
+            m = fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype)
+            return x1, a + m, present
+        x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias)
+        g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
+        return x2, fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype), present
+
 
 def strip_reference_buffers(state_dict):
     """Reference checkpoints carry mask buffers (bias / self_bias / masked_bias) and, when saved from DDP,
@@ -247,7 +281,7 @@ class _LMBase(nn.Module):
 
     def supportsMergedTree(self, input_ids):
         """Can text and tree nodes go through ONE forward (BranchPast.merged_text)?  Only on the fused block path."""
-        return _fused_eligible(self, input_ids, None, None, False)
+        return getattr(self, "_fused_family", None) == "gpt2" and _fused_eligible(self, input_ids, None, None, False)
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         """Accepts reference checkpoints: drops their mask buffers (bias / self_bias / masked_bias)."""
@@ -292,6 +326,7 @@ def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidd
 
 class GPTNeoXForCausalLM(_LMBase):
     """NeoXNonResidualBase.py:303-400: LM head `embed_out` or 1-unit `valueHead`, chosen by returnLmLogits."""
+    _fused_family = "neox"
 
     def __init__(self, config):
         super().__init__()
@@ -310,6 +345,20 @@ class GPTNeoXForCausalLM(_LMBase):
         B, T = input_ids.shape
         pos = _positions(position_ids, B, T, input_ids.device)
         branch = textualPast is not None
+        if _fused_eligible(self, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate) and \
+                not (branch and getattr(textualPast, "merged_text", 0)):
+            dtype = fused.compute_dtype(self.gpt_neox.embed_in.weight)
+            fused.prepare_weights(self, dtype)
+            with torch.autocast("cuda", enabled=False):
+                x, delta, presents = fused.embedding(input_ids, None, self.gpt_neox.embed_in.weight), None, []
+                for i, layer in enumerate(self.gpt_neox.layers):
+                    x, delta, present = layer.fused_forward(x, delta, dtype, pos, _layer_past(textualPast, i) if branch else None)
+                    presents.append(present)
+                _, y = fused.add_layer_norm(x, delta, self.gpt_neox.final_layer_norm, dtype)
+                head = self.embed_out if returnLmLogits else self.valueHead
+                logits = fused.linear(y, head.weight, None, "oi", dtype)
+            return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,
+                                   hidden_states=None, attentions=None, last_hidden_state=y)
         x = self.gpt_neox.embed_in(input_ids)
         hidden_dropout = self.config.resid_pdrop
         if hidden_dropout:

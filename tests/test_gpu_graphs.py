@@ -59,3 +59,13 @@ def test_graphed_step_matches_eager(amp, defer_d, monkeypatch):
     ptol = dict(rtol=1e-4, atol=1e-6) if amp is None else dict(rtol=0, atol=2.5e-3)      # bf16: Adam steps of 1e-3 can flip sign
     for k, v in model.state_dict().items():
         torch.testing.assert_close(v, ref[k], msg=lambda m: f"{k}: {m}", **ptol)
+
+
+def test_graph_capture_requires_the_fused_path(monkeypatch):
+    """The module-by-module path is eager-only (graphs._require_fused_path explains why)."""
+    from branchgan import fused
+    model, conf, rl, g_opt, d_opt = _setup()
+    ids = torch.randint(0, 100, (4, 64), device="cuda")
+    monkeypatch.setattr(fused, "ENABLED", False)
+    with pytest.raises(NotImplementedError, match="fused block path"):
+        GraphedTrainStep(model, conf, g_opt, d_opt, ids, 9999, rl, None)
