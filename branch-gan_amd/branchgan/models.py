@@ -82,11 +82,9 @@ def branch_attention_core(q, k, v, lp, scale):
     """q, k, v (B,H,NQ*K,Dh) of the new tokens; lp = layer view of a BranchPast.  -> (B,H,NQ*K,Dh)."""
     NQ = lp.n_query_nodes
     K = q.shape[2] // NQ
-    q5 = q.unflatten(2, (NQ, K))
-    k5, v5 = k.unflatten(2, (NQ, K)), v.unflatten(2, (NQ, K))
-    slots_k = [a[0] for a in lp.ancestors] + [k5[:, :, n] for n in range(NQ)]
-    slots_v = [a[1] for a in lp.ancestors] + [v5[:, :, n] for n in range(NQ)]
-    out, _ = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, slots_k, slots_v, paths=lp.paths, scale=scale)
+    q5, k5, v5 = q.unflatten(2, (NQ, K)), k.unflatten(2, (NQ, K)), v.unflatten(2, (NQ, K))
+    out, _ = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, [a[0] for a in lp.ancestors], [a[1] for a in lp.ancestors],
+                                  paths=lp.paths, scale=scale, own_k=k5, own_v=v5)
     return out.flatten(2, 3)
 
 

@@ -203,72 +203,108 @@ def _unit_last(t):
 
 
 class _BranchAttention(torch.autograd.Function):
+    """own_k / own_v (optional, (B,H,NQ,K,Dh)): the keys / values of the query nodes themselves, ONE tensor for all nodes.
+    They become slots n_slots .. n_slots + NQ - 1 as views made in here, so autograd sees one input and backward returns one
+    gradient tensor (slicing them outside costs a zero-fill, a copy and an add per node, per layer, for k and for v)."""
+
     @staticmethod
-    def forward(ctx, q, k_text, v_text, ctx_len, path, path_len, max_path, scale, n_slots, *slots):
+    def forward(ctx, q, k_text, v_text, ctx_len, path, path_len, max_path, scale, n_slots, own_k, own_v, *slots):
         slots_k, slots_v = list(slots[:n_slots]), list(slots[n_slots:])
         C.require_cuda(q, k_text, v_text, ctx_len, *slots)
         q = _unit_last(q)
         k_text, v_text = _unit_last(k_text), _unit_last(v_text)
         if k_text.stride() != v_text.stride():
             k_text, v_text = k_text.contiguous(), v_text.contiguous()
+        B, H, NQ, K, Dh = q.shape
+        if own_k is not None:
+            C.require_cuda(own_k, own_v)
+            if own_k.stride() != own_v.stride() or own_k.stride(-1) != 1:
+                own_k, own_v = own_k.contiguous(), own_v.contiguous()
+            slots_k = slots_k + [own_k[:, :, n] for n in range(NQ)]
+            slots_v = slots_v + [own_v[:, :, n] for n in range(NQ)]
         if slots_k:
             ref = slots_k[0].stride()
             if any(t.stride() != ref or t.stride(-1) != 1 for t in slots_k + slots_v):
+                if own_k is not None:
+                    raise NotImplementedError("ancestor slots must share the layout of the query nodes' own keys / values")
                 slots_k = [t.contiguous() for t in slots_k]
                 slots_v = [t.contiguous() for t in slots_v]
-        B, H, NQ, K, Dh = q.shape
-        out = torch.empty((B, H, NQ, K, Dh), dtype=q.dtype, device=q.device)
+        # (B, NQ, K, H, Dh) in memory: the projection that follows reads it as (B, NQ*K, H*Dh) with no permute copy
+        out = torch.empty((B, NQ, K, H, Dh), dtype=q.dtype, device=q.device).permute(0, 3, 1, 2, 4)
         lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=q.device)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
         with _timed("branch_attn_fwd"):
             C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
                                                _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
                                                C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
-        ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots_k, *slots_v)
-        ctx.meta = (max_path, scale, len(slots_k))
+        has_own = own_k is not None
+        ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots[:n_slots], *slots[n_slots:],
+                              *((own_k, own_v) if has_own else ()))
+        ctx.meta = (max_path, scale, n_slots, has_own)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
-        max_path, scale, n_slots = ctx.meta
+        max_path, scale, n_slots, has_own = ctx.meta
         q, k_text, v_text, ctx_len, path, path_len, out, lse = ctx.saved_tensors[:8]
-        slots_k = list(ctx.saved_tensors[8:8 + n_slots])
-        slots_v = list(ctx.saved_tensors[8 + n_slots:])
-        dout = dout.contiguous()
-        dq = torch.empty_like(out)
-        dk_text = torch.empty_strided(k_text.shape, k_text.stride(), dtype=k_text.dtype, device=k_text.device)
-        dv_text = torch.empty_strided(k_text.shape, k_text.stride(), dtype=k_text.dtype, device=k_text.device)
-        dks = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in slots_k]
-        dvs = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in slots_k]
+        anc_k = list(ctx.saved_tensors[8:8 + n_slots])
+        anc_v = list(ctx.saved_tensors[8 + n_slots:8 + 2 * n_slots])
+        B, H, NQ, K, Dh = q.shape
+        like = lambda t: torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+        d_anc_k, d_anc_v = [like(t) for t in anc_k], [like(t) for t in anc_k]
+        slots_k, slots_v, dks, dvs = anc_k, anc_v, list(d_anc_k), list(d_anc_v)
+        d_own_k = d_own_v = None
+        if has_own:
+            own_k, own_v = ctx.saved_tensors[8 + 2 * n_slots:]
+            d_own_k, d_own_v = like(own_k), like(own_k)
+            slots_k = slots_k + [own_k[:, :, n] for n in range(NQ)]
+            slots_v = slots_v + [own_v[:, :, n] for n in range(NQ)]
+            dks += [d_own_k[:, :, n] for n in range(NQ)]
+            dvs += [d_own_v[:, :, n] for n in range(NQ)]
+        if slots_k and any(t.stride() != slots_k[0].stride() for t in slots_k + slots_v):      # forward made them contiguous
+            slots_k, slots_v = [t.contiguous() for t in slots_k], [t.contiguous() for t in slots_v]
+            dks, dvs = [torch.empty_like(t) for t in slots_k], [torch.empty_like(t) for t in slots_k]
+            d_anc_k, d_anc_v = dks[:n_slots], dvs[:n_slots]
+        if dout.stride() != out.stride():
+            dout = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device).copy_(dout)
+        dq = torch.empty((B, H, NQ, K, Dh), dtype=q.dtype, device=q.device)
+        dk_text, dv_text = like(k_text), like(k_text)
         delta = torch.empty_like(lse)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
+        sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq.stride()[:4]
         with _timed("branch_attn_bwd"):
             C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
                                                _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
                                                C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text), None, None,
                                                _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
                     "bg_branch_attn_bwd")
-        return (dq, dk_text, dv_text, None, None, None, None, None, None, *dks, *dvs)
+        return (dq, dk_text, dv_text, None, None, None, None, None, None, d_own_k, d_own_v, *d_anc_k, *d_anc_v)
 
 
-def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=None, scale=None):
+def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=None, scale=None, own_k=None, own_v=None):
     """q (B,H,NQ,K,Dh) [or (B,H,K,Dh) = one node]; k_text/v_text (B,H,S,Dh); ctx_len int32 (K,) device;
-    slots_k/v: lists of (B,H,K,Dh); paths: per query node, the slot indices it may see (ancestors + itself).
-    Returns (out like q, lse fp32)."""
+    slots_k/v: lists of (B,H,K,Dh); own_k/own_v (optional, (B,H,NQ,K,Dh)): the query nodes' own keys / values, which become
+    the slots after slots_k (slot len(slots_k) + n = node n); paths: per query node, the slot indices it may see (ancestors
+    + itself).  Returns (out like q [a (B,NQ,K,H,Dh)-contiguous view], lse fp32)."""
     squeeze = q.dim() == 4
     if squeeze:
         q = q.unsqueeze(2)
     NQ = q.shape[2]
+    n_total = len(slots_k) + (NQ if own_k is not None else 0)
     if paths is None:
-        paths = [list(range(len(slots_k)))] * NQ
+        paths = [list(range(n_total))] * NQ
     if len(paths) != NQ:
         raise ValueError(f"{len(paths)} paths for {NQ} query nodes")
     for p in paths:
-        if any(s < 0 or s >= len(slots_k) for s in p):
+        if any(s < 0 or s >= n_total for s in p):
             raise ValueError("path refers to a slot that was not passed")
     if len(slots_k) != len(slots_v):
         raise ValueError("slots_k and slots_v differ in length")
+    if (own_k is None) != (own_v is None) or (own_k is not None and (own_k.shape != q.shape or own_v.shape != q.shape)):
+        raise ValueError("own_k / own_v must both be given, shaped like q")
+    if n_total > C.MAX_SLOTS:
+        raise ValueError(f"{n_total} slots (max {C.MAX_SLOTS})")
     if ctx_len.dtype != torch.int32 or ctx_len.numel() != q.shape[3]:
         raise ValueError("ctx_len must be int32 with one entry per branch point")
     if k_text.shape[-1] != q.shape[-1]:
@@ -277,7 +313,7 @@ def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=N
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     out, lse = _BranchAttention.apply(q, k_text, v_text, ctx_len.contiguous(), path, path_len, max_path, float(scale),
-                                      len(slots_k), *slots_k, *slots_v)
+                                      len(slots_k), own_k, own_v, *slots_k, *slots_v)
     return (out.squeeze(2), lse.squeeze(2)) if squeeze else (out, lse)
 
 
