@@ -172,14 +172,14 @@ def supported_width(C_):
 # ---------------------------------------------------------------------------------------------------------------------
 # LayerNorm (+ residual add)
 # ---------------------------------------------------------------------------------------------------------------------
-def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype):
+def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None):
     rows, C_ = x2.shape
     y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
     x_out = torch.empty_like(x2) if delta2 is not None else None
     with ops._timed("add_layernorm_fwd"):
-        C.check(C.lib().bg_add_layernorm_fwd(C.ptr(x2), C.ptr(delta2), C.dtype_code(delta2) if delta2 is not None else 0, rows, C_,
+        C.check(C.lib().bg_add_layernorm_fwd(C.ptr(x2), C.ptr(delta2), C.ptr(second), C.dtype_code(delta2) if delta2 is not None else 0, rows, C_,
                                              C.ptr(gamma), C.ptr(beta), float(eps), C.ptr(x_out), C.ptr(y), C.dtype_code(y),
                                              C.ptr(mean), C.ptr(rstd), C.stream_ptr()), "bg_add_layernorm_fwd")
     return x_out, y, mean, rstd
@@ -220,14 +220,17 @@ class _LayerNorm(torch.autograd.Function):
 
 
 class _AddLayerNorm(torch.autograd.Function):
-    """delta_bias (optional): the bias parameter of the projection that produced `delta`.  Its gradient is the column sum of
+    """delta_b (optional): a second update added in the same pass (x + delta + delta_b: the attention and MLP outputs of a
+    parallel-residual block); both get the same gradient.  delta_bias (optional): the bias parameter of the projection that produced `delta`.  Its gradient is the column sum of
     delta's gradient, which this backward has in registers anyway - the projection is then built with bias_grad=False."""
 
     @staticmethod
-    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias):
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias, delta_b):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         d2 = delta.reshape(x2.shape).contiguous()
-        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype)
+        db2 = delta_b.reshape(x2.shape).to(delta.dtype).contiguous() if delta_b is not None else None
+        ctx.two = delta_b is not None
+        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype, db2)
         ctx.save_for_backward(x_out, mean, rstd)
         ctx.params = (gamma, beta, delta_bias)
         ctx.delta_dtype = delta.dtype
@@ -241,7 +244,7 @@ class _AddLayerNorm(torch.autograd.Function):
         if delta_bias is not None and not delta_bias.requires_grad:
             delta_bias = None
         if dy is None and dx_new is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         if dy is None:      # only the residual output was used
             dres = dx_new.reshape(x_out.shape).contiguous().float()
             dlp = dres.to(ctx.delta_dtype)
@@ -249,21 +252,22 @@ class _AddLayerNorm(torch.autograd.Function):
             if delta_bias is not None:
                 buf, dc_ret = _grad_buffer(delta_bias)
                 buf.add_(dlp.float().sum(0))
-            return dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret
+            return dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret, (dlp.view(dx_new.shape) if ctx.two else None)
         dres2 = dx_new.reshape(x_out.shape).contiguous().float() if dx_new is not None else None
         dx, dx_lp, dg, db, dc = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype,
                                         delta_bias)
         shape = dy.shape
-        return dx.view(shape), (dx_lp if dx_lp is not None else dx).view(shape), dg, db, None, None, dc
+        dd = (dx_lp if dx_lp is not None else dx).view(shape)
+        return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None)
 
 
 def layer_norm(x, ln, out_dtype):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype)
 
 
-def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None):
-    """-> (x + delta [fp32], LayerNorm(x + delta) [out_dtype]).  delta_bias: see _AddLayerNorm."""
-    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias)
+def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None, delta_b=None):
+    """-> (x + delta [+ delta_b] [fp32], LayerNorm of it [out_dtype]).  delta_bias, delta_b: see _AddLayerNorm."""
+    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias, delta_b)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -236,10 +236,13 @@ class GPTNeoXLayer(nn.Module):
 
     def fused_forward(self, x, delta, dtype, pos, lp):
         """Same block on the fused path (see NonResidualGPT2Block.fused_forward).  `x` is the fp32 residual stream BEFORE the
-        previous block's update `delta` (None for the first block); returns (x + delta, this block's update, present).
+        previous block's update `delta` (None for the first block; a pair (attention, MLP) after a parallel-residual block,
+        added in the LayerNorm kernel); returns (x + delta, this block's update, present).
         Parallel residual: both LayerNorms read x + delta, the update is attention + MLP."""
         if delta is None:
             x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype)
+        elif isinstance(delta, tuple):
+            x1, h1 = fused.add_layer_norm(x, delta[0], self.input_layernorm, dtype, delta_b=delta[1])
         else:
             x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype)
         a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
@@ -247,7 +250,7 @@ class GPTNeoXLayer(nn.Module):
             h2 = fused.layer_norm(x1, self.post_attention_layernorm, dtype)
             g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
             m = fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype)
-            return x1, a + m, present
+            return x1, (a, m), present
         x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias)
         g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
         return x2, fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype), present
@@ -347,12 +350,16 @@ class GPTNeoXForCausalLM(_LMBase):
                 not (branch and getattr(textualPast, "merged_text", 0)):
             dtype = fused.compute_dtype(self.gpt_neox.embed_in.weight)
             fused.prepare_weights(self, dtype)
+            pos = pos.contiguous()          # once, not per layer (an expanded view otherwise)
             with torch.autocast("cuda", enabled=False):
                 x, delta, presents = fused.embedding(input_ids, None, self.gpt_neox.embed_in.weight), None, []
                 for i, layer in enumerate(self.gpt_neox.layers):
                     x, delta, present = layer.fused_forward(x, delta, dtype, pos, _layer_past(textualPast, i) if branch else None)
                     presents.append(present)
-                _, y = fused.add_layer_norm(x, delta, self.gpt_neox.final_layer_norm, dtype)
+                if isinstance(delta, tuple):
+                    _, y = fused.add_layer_norm(x, delta[0], self.gpt_neox.final_layer_norm, dtype, delta_b=delta[1])
+                else:
+                    _, y = fused.add_layer_norm(x, delta, self.gpt_neox.final_layer_norm, dtype)
                 head = self.embed_out if returnLmLogits else self.valueHead
                 logits = fused.linear(y, head.weight, None, "oi", dtype)
             return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,

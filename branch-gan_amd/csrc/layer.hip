@@ -40,6 +40,7 @@ __device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
 struct LnFwdArgs {
   const float* x;
   const void* delta;
+  const void* delta2;   // optional second update of the same dtype (parallel-residual blocks: attention + MLP)
   const float* gamma;
   const float* beta;
   float* x_out;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
   const int C = a.C;
   const float* x = a.x + r * C;
   const TD* d = a.delta ? (const TD*)a.delta + r * C : nullptr;
+  const TD* d2 = a.delta2 ? (const TD*)a.delta2 + r * C : nullptr;
   float v[NV][4];
   float s = 0.f;
 #pragma unroll
@@ -74,6 +76,11 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
         load4<TD>(d + c, dv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
+        if (d2) {
+          load4<TD>(d2 + c, dv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
+        }
         store4<float>(a.x_out + r * C + c, v[i]);
       }
 #pragma unroll
@@ -341,7 +348,7 @@ using namespace bg;
 static bool dtype_ok(int d) { return d == BG_F32 || d == BG_BF16; }
 static bool al16(const void* p) { return p && (((uintptr_t)p) & 15) == 0; }
 
-extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C, const float* gamma,
+extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C, const float* gamma,
                                     const float* beta, float eps, float* x_out, void* y, int y_dtype, float* mean, float* rstd,
                                     void* stream) {
   BG_REQUIRE(x && gamma && beta && y && mean && rstd, "bg_add_layernorm_fwd: null argument");
@@ -349,9 +356,10 @@ extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, int delta
   BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_add_layernorm_fwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
   BG_REQUIRE(dtype_ok(y_dtype) && (!delta || dtype_ok(delta_dtype)), "bg_add_layernorm_fwd: dtype");
   BG_REQUIRE(!delta || x_out, "bg_add_layernorm_fwd: delta without x_out");
+  BG_REQUIRE(!delta2 || (delta && (((uintptr_t)delta2) & 7) == 0), "bg_add_layernorm_fwd: delta2 without delta, or misaligned");
   BG_REQUIRE(al16(x) && al16(gamma) && al16(beta) && (!delta || (((uintptr_t)delta) & 7) == 0) && (!delta || al16(x_out)) && (((uintptr_t)y) & 7) == 0,
              "bg_add_layernorm_fwd: pointers must be 16-byte aligned (8 for bf16)");
-  LnFwdArgs a{x, delta, gamma, beta, x_out, y, mean, rstd, rows, C, eps};
+  LnFwdArgs a{x, delta, delta2, gamma, beta, x_out, y, mean, rstd, rows, C, eps};
   hipStream_t st = (hipStream_t)stream;
   const bool dbf = delta && delta_dtype == BG_BF16;
   if (y_dtype == BG_BF16) {

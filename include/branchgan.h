@@ -167,7 +167,8 @@ int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dty
  * Models/NeoXBranchAttention/NeoXNonResidualBase.py:108-133, and in backward the separate cast, residual-add,
  * LayerNorm dgamma/dbeta and bias-gradient reductions autograd launches for them.
  *
- * bg_add_layernorm_fwd:  xn = x + delta (delta may be NULL: xn = x, x_out untouched);  x_out = xn;
+ * bg_add_layernorm_fwd:  xn = x + delta [+ delta2] (delta may be NULL: xn = x, x_out untouched; delta2, optional, is the
+ *   second update of a parallel-residual block, same dtype and shape as delta);  x_out = xn;
  *   y = (xn - mean) * rstd * gamma + beta, mean / rstd per row (biased variance, eps inside the root).
  *   x, x_out fp32 [rows][C]; delta [rows][C] of delta_dtype; y [rows][C] of y_dtype; mean, rstd fp32 [rows].
  * bg_layernorm_bwd:  dx = dres + LayerNorm'(dy) (dres may be NULL); dx_lp (optional) = dx rounded to lp_dtype
@@ -179,7 +180,7 @@ int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dty
  * C % 4 == 0; LayerNorm: C <= 4096.  The column reductions are deterministic (per-workgroup partials in the
  * workspace, added in a fixed order) and ACCUMULATE into the fp32 gradients.
  */
-int bg_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C,
+int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
                          const float* gamma, const float* beta, float eps,
                          float* x_out, void* y, int y_dtype, float* mean, float* rstd, void* stream);
 size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C);

@@ -239,3 +239,32 @@ def test_attention_backward_adds_incoming_text_gradients(dt):
         tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=2 ** -7, atol=2 ** -7)
         torch.testing.assert_close(dk1, dk0 + ik.float(), **tol)
         torch.testing.assert_close(dv1, dv0 + iv.float(), **tol)
+
+
+@pytest.mark.parametrize("lowp", [False, True])
+def test_add_layernorm_with_two_updates(lowp):
+    """add_layer_norm(x, a, ln, delta_b=m) = LayerNorm(x + a + m) of a parallel-residual block (NeoXNonResidualBase.py:108-133:
+    `mlp + attn + hidden`), both updates receiving the same gradient.  fp32: 1e-5; bf16 updates: the sum is formed in fp32
+    here and in bf16 by the reference, so within one bf16 rounding of the updates."""
+    from branchgan import fused
+    torch.manual_seed(5)
+    rows, C = 300, 512
+    dt = torch.bfloat16 if lowp else torch.float32
+    x = torch.randn(rows, C, device="cuda", requires_grad=True)
+    a = torch.randn(rows, C, device="cuda").to(dt).requires_grad_(True)
+    m = torch.randn(rows, C, device="cuda").to(dt).requires_grad_(True)
+    ln = torch.nn.LayerNorm(C).cuda()
+    x_new, y = fused.add_layer_norm(x, a, ln, dt, delta_b=m)
+    gx, gy = torch.randn_like(x_new), torch.randn(rows, C, device="cuda").to(dt)
+    torch.autograd.backward([x_new, y], [gx, gy])
+    xr, ar, mr = x.detach().clone().requires_grad_(True), a.detach().float().requires_grad_(True), m.detach().float().requires_grad_(True)
+    lr = torch.nn.LayerNorm(C).cuda()
+    xs = mr + ar + xr
+    yr = lr(xs)
+    torch.autograd.backward([xs, yr], [gx, gy.float()])
+    torch.testing.assert_close(x_new, xs, rtol=1e-6, atol=1e-5)
+    tol = dict(atol=3e-2, rtol=2 ** -7) if lowp else dict(atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(y.float(), yr, **tol)
+    torch.testing.assert_close(x.grad, xr.grad, atol=2e-4, rtol=1e-4)
+    assert torch.equal(a.grad, m.grad)
+    torch.testing.assert_close(a.grad.float(), ar.grad, **(dict(atol=3e-2, rtol=2 ** -7) if lowp else dict(atol=2e-4, rtol=1e-4)))
