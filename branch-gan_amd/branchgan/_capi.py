@@ -38,6 +38,10 @@ class RlLossShape(ctypes.Structure):
                 ("ignore_input", c_i32), ("ignore_alt", c_i32), ("use_depth_mask", c_i32), ("probs_input", c_i32)]
 
 
+class ReduceDesc(ctypes.Structure):
+    _fields_ = [("partial", c_vp), ("out", c_vp), ("groups", c_i32), ("stride", c_i32), ("n", c_i32), ("reserved", c_i32)]
+
+
 # name -> (restype, argtypes); every symbol include/branchgan.h declares
 SIGNATURES = {
     "bg_last_error": (ctypes.c_char_p, []),
@@ -59,7 +63,11 @@ SIGNATURES = {
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
-    "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz,
+                                 c_vp]),
+    "bg_layernorm_bwd_groups": (c_i32, [c_i64]),
+    "bg_bias_act_bwd_groups": (c_i32, [c_i64]),
+    "bg_partial_reduce": (c_i32, [ctypes.POINTER(ReduceDesc), c_i32, c_vp]),
     "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_embed_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),

@@ -165,6 +165,82 @@ def _workspace(nbytes, device):
     return ws
 
 
+# Column reductions (LayerNorm dgamma / dbeta, bias gradients) end in a small second kernel that adds per-workgroup partials
+# into the fp32 gradient.  Nothing inside a backward pass reads those gradients, so the reduction launches (4 per transformer
+# block, ~5 us each, latency-bound) are collected and run as ONE batched launch per ~96 reductions when the backward pass
+# ends (an autograd-engine callback: `loss.backward()` returns with complete gradients, nothing for callers to remember).
+# BRANCHGAN_DEFER_REDUCE=0 reduces behind every producer again.
+DEFER_REDUCTIONS = os.environ.get("BRANCHGAN_DEFER_REDUCE", "1") != "0"
+
+
+class _DeferredReductions:
+    """Per device: a grow-only list of chunks the producers' partials are bump-allocated from, and the reductions waiting."""
+    CHUNK = 64 << 20
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks, self.cur, self.off = [], 0, 0
+        self.pending, self.streams, self.armed = [], set(), False
+
+    def begin(self):
+        """Called by a producer about to defer.  False: not inside a backward pass (no engine callback possible), reduce now."""
+        if self.armed:
+            return True
+        self.pending.clear()            # leftovers of a backward pass that raised before its callback ran
+        self.streams.clear()
+        self.cur = self.off = 0
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        except RuntimeError:
+            return False
+        self.armed = True
+        return True
+
+    def alloc(self, nbytes):
+        nbytes = (int(nbytes) + 255) & ~255
+        while True:
+            if self.cur == len(self.chunks):
+                self.chunks.append(torch.empty(max(self.CHUNK, nbytes), dtype=torch.uint8, device=self.device))
+            chunk = self.chunks[self.cur]
+            if self.off + nbytes <= chunk.numel():
+                view = chunk[self.off:self.off + nbytes]
+                self.off += nbytes
+                return view
+            self.cur, self.off = self.cur + 1, 0
+
+    def add(self, partial_ptr, out, groups, stride, n):
+        self.pending.append((partial_ptr, out, groups, stride, n))
+        self.streams.add(torch.cuda.current_stream(self.device))
+
+    def flush(self):
+        self.armed = False
+        pending, self.pending = self.pending, []
+        streams, self.streams = self.streams, set()
+        self.cur = self.off = 0
+        if not pending:
+            return
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            for st in streams:
+                if st != cur:
+                    cur.wait_stream(st)
+            descs = (C.ReduceDesc * len(pending))()
+            for d, (pp, out, groups, stride, n) in zip(descs, pending):
+                d.partial, d.out, d.groups, d.stride, d.n = pp, out.data_ptr(), groups, stride, n
+            with ops._timed("partial_reduce"):
+                C.check(C.lib().bg_partial_reduce(descs, len(pending), C.stream_ptr()), "bg_partial_reduce")
+
+
+_deferred = {}
+
+
+def _deferred_for(device):
+    d = _deferred.get(device)
+    if d is None:
+        d = _deferred[device] = _DeferredReductions(device)
+    return d
+
+
 def supported_width(C_):
     return C_ % 8 == 0 and C_ <= 4096
 
@@ -194,11 +270,20 @@ def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None
     dc, dc_ret = _grad_buffer(colsum_p) if colsum_p is not None else (None, None)
     lib = C.lib()
     nbytes = lib.bg_layernorm_bwd_workspace_bytes(rows, C_)
-    ws = _workspace(nbytes, x2.device)
+    later = _deferred_for(x2.device) if DEFER_REDUCTIONS and dg_ret is None and db_ret is None and dc_ret is None else None
+    if later is not None and not later.begin():
+        later = None
+    ws = later.alloc(nbytes) if later is not None else _workspace(nbytes, x2.device)
     with ops._timed("layernorm_bwd"):
         C.check(lib.bg_layernorm_bwd(C.ptr(dy2), C.dtype_code(dy2), C.ptr(x2), C.ptr(mean), C.ptr(rstd), C.ptr(gamma_p.detach()),
                                      C.ptr(dres2), rows, C_, C.ptr(dx), C.ptr(dx_lp), C.dtype_code(dx_lp) if dx_lp is not None else 0,
-                                     C.ptr(dg), C.ptr(db), C.ptr(dc), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
+                                     *((None, None, None, int(dc is not None)) if later is not None else (C.ptr(dg), C.ptr(db), C.ptr(dc), 0)),
+                                     C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
+    if later is not None:
+        groups, stride, base = lib.bg_layernorm_bwd_groups(rows), (3 if dc is not None else 2) * C_, ws.data_ptr()
+        for i, out in enumerate((dg, db, dc)):
+            if out is not None:
+                later.add(base + 4 * C_ * i, out, groups, stride, C_)
     return dx, dx_lp, dg_ret, db_ret, dc_ret
 
 
@@ -392,14 +477,20 @@ class _Linear(torch.autograd.Function):
                 dpre = torch.empty_like(pre)
             else:
                 dpre = None
+            db = None                       # no bias (or not ours to differentiate): the partial sums are simply never reduced
             if bias is not None:
                 db, db_ret = _grad_buffer(bias)
-            else:
-                db = torch.zeros(n_out, dtype=torch.float32, device=dy2.device)
-            ws = _workspace(lib.bg_bias_act_bwd_workspace_bytes(rows, n_out), dy2.device)
+            nbytes = lib.bg_bias_act_bwd_workspace_bytes(rows, n_out)
+            later = _deferred_for(dy2.device) if DEFER_REDUCTIONS and db is not None and db_ret is None else None
+            if later is not None and not later.begin():
+                later = None
+            ws = later.alloc(nbytes) if later is not None else _workspace(nbytes, dy2.device)
             with ops._timed("bias_act_bwd"):
                 C.check(lib.bg_bias_act_bwd(C.ptr(dy2), C.dtype_code(dy2), rows, n_out, dy2.stride(0), _ACT[act], C.ptr(pre),
-                                            C.ptr(dpre), C.ptr(db), C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_bias_act_bwd")
+                                            C.ptr(dpre), None if later is not None else C.ptr(db), C.ptr(ws), ws.numel(), C.stream_ptr()),
+                        "bg_bias_act_bwd")
+            if later is not None:
+                later.add(ws.data_ptr(), db, lib.bg_bias_act_bwd_groups(rows), n_out, n_out)
             if dpre is not None:
                 dy2 = dpre
         w = lowp(weight, dtype)

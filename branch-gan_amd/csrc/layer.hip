@@ -11,6 +11,8 @@
 // second small kernel adds them in a fixed order into the fp32 gradient (accumulating: grad += sum).
 #include "common.h"
 
+#include <vector>
+
 namespace bg {
 
 #define LN_MAX_NV 16   // 16-byte fp32 vectors per lane: C <= 64 * 4 * 16 = 4096
@@ -231,19 +233,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
   for (int c = threadIdx.x; c < NP * C; c += 256) part[c] = lds[c];
 }
 
-// out0[c] += sum_g partial[g][c] (c < n0), out1[c - n0] += ... (n0 <= c < n0 + n1), out2 likewise.  256 threads = 32 columns
+// out[c] += sum_g partial[g * stride + c] for each of up to REDUCE_BATCH descriptors in one launch.  256 threads = 32 columns
 // x 8 slices of g; every thread adds its slice in increasing g, then the 8 slice sums are added in slice order: a fixed
-// summation order.
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partial, int G, int n0, int n1, int n2, float* out0, float* out1,
-                                                             float* out2) {
+// summation order, the same whether a descriptor is reduced right behind its producer or with hundreds of others at the end
+// of a backward pass (bg_partial_reduce).
+constexpr int REDUCE_BATCH = 96;
+struct ReduceDesc {
+  const float* partial;
+  float* out;
+  int G, stride, n, first_block;      // first_block: prefix sum of cdiv(n, 32) over the descriptors before this one
+};
+struct ReduceBatch {
+  ReduceDesc d[REDUCE_BATCH];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceBatch b) {
   __shared__ float red[8][33];
+  int lo = 0, hi = b.count - 1;          // the last descriptor whose first_block <= blockIdx.x (uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.d[mid].first_block <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const float* partial = b.d[lo].partial;
+  float* out = b.d[lo].out;
+  const int G = b.d[lo].G, stride = b.d[lo].stride, n = b.d[lo].n;
   const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + col;
-  const int n = n0 + n1 + n2;
+  const int c = ((int)blockIdx.x - b.d[lo].first_block) * 32 + col;
   float s = 0.f;
   if (c < n) {
 #pragma unroll 8
-    for (int g = slice; g < G; g += 8) s += partial[(int64_t)g * n + c];
+    for (int g = slice; g < G; g += 8) s += partial[(int64_t)g * stride + c];
   }
   red[slice][col] = s;
   __syncthreads();
@@ -251,10 +272,45 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* partia
     float t = red[0][col];
 #pragma unroll
     for (int k = 1; k < 8; ++k) t += red[k][col];
-    if (c < n0) out0[c] += t;
-    else if (c < n0 + n1) out1[c - n0] += t;
-    else out2[c - n0 - n1] += t;
+    out[c] += t;
   }
+}
+
+// host side: packs descriptors into launches of REDUCE_BATCH.
+struct ReduceItem {
+  const float* partial;
+  float* out;
+  int G, stride, n;
+};
+// Reductions into the same (or an overlapping) `out` must not share a launch: item i goes into round r(i) = 1 + the highest
+// round among the earlier items it overlaps, and the rounds run one after another - every `out` receives its partial sums in
+// the order the items were given.
+static int launch_reduce(const ReduceItem* items, int count, hipStream_t st) {
+  std::vector<int> round((size_t)count, 0);
+  int rounds = 1;
+  for (int i = 1; i < count; ++i) {
+    for (int j = 0; j < i; ++j) {
+      if (items[i].out < items[j].out + items[j].n && items[j].out < items[i].out + items[i].n && round[j] + 1 > round[i]) round[i] = round[j] + 1;
+    }
+    if (round[i] + 1 > rounds) rounds = round[i] + 1;
+  }
+  for (int r = 0; r < rounds; ++r) {
+    ReduceBatch b;
+    int m = 0, blocks = 0;
+    for (int i = 0; i <= count; ++i) {
+      if (i < count && round[i] == r) {
+        const ReduceItem& it = items[i];
+        b.d[m++] = ReduceDesc{it.partial, it.out, it.G, it.stride, it.n, blocks};
+        blocks += (int)cdiv(it.n, 32);
+      }
+      if (m == REDUCE_BATCH || (i == count && m > 0)) {
+        b.count = m;
+        hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+        m = blocks = 0;
+      }
+    }
+  }
+  return 0;
 }
 
 // ---- bias gradient (column sums) with the activation's backward in the same pass ------------------------------------------
@@ -382,10 +438,15 @@ extern "C" size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
   return (size_t)ln_groups(rows) * 3 * (size_t)C * sizeof(float);
 }
 
+extern "C" int bg_layernorm_bwd_groups(int64_t rows) { return rows > 0 ? ln_groups(rows) : 0; }
+
 extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
-                                float* dbeta, float* dx_colsum, void* workspace, size_t workspace_bytes, void* stream) {
-  BG_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "bg_layernorm_bwd: null argument");
+                                float* dbeta, float* dx_colsum, int deferred_colsum, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  BG_REQUIRE(dy && x && mean && rstd && gamma && dx, "bg_layernorm_bwd: null argument");
+  BG_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "bg_layernorm_bwd: dgamma and dbeta are given together, or both NULL (deferred reduction)");
+  BG_REQUIRE(deferred_colsum == 0 || !dgamma, "bg_layernorm_bwd: deferred_colsum is for the deferred form (dgamma == NULL)");
   BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_layernorm_bwd: rows=%lld", (long long)rows);
   BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_layernorm_bwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
   BG_REQUIRE(dtype_ok(dy_dtype) && (!dx_lp || dtype_ok(lp_dtype)), "bg_layernorm_bwd: dtype");
@@ -397,7 +458,7 @@ extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     return BG_ERR_WORKSPACE;
   }
   const int G = ln_groups(rows);
-  const bool colsum = dx_colsum != nullptr;
+  const bool colsum = dx_colsum != nullptr || deferred_colsum != 0;
   LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, dx_lp, (float*)workspace, rows, C};
   hipStream_t st = (hipStream_t)stream;
   const bool lbf = dx_lp && lp_dtype == BG_BF16;
@@ -409,9 +470,13 @@ extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     else launch_ln_bwd<float, float>(a, G, colsum, st);
   }
   BG_CHECK_LAUNCH("bg_layernorm_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv((colsum ? 3 : 2) * C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, C,
-                     colsum ? C : 0, dgamma, dbeta, dx_colsum);
-  BG_CHECK_LAUNCH("bg_layernorm_bwd(reduce)");
+  if (dgamma) {
+    const float* part = (const float*)workspace;
+    const int stride = (colsum ? 3 : 2) * C;
+    const ReduceItem items[3] = {{part, dgamma, G, stride, C}, {part + C, dbeta, G, stride, C}, {part + 2 * C, dx_colsum, G, stride, C}};
+    launch_reduce(items, colsum ? 3 : 2, st);
+    BG_CHECK_LAUNCH("bg_layernorm_bwd(reduce)");
+  }
   return BG_OK;
 }
 
@@ -420,9 +485,11 @@ extern "C" size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C) {
   return (size_t)bias_groups(rows) * (size_t)C * sizeof(float);
 }
 
+extern "C" int bg_bias_act_bwd_groups(int64_t rows) { return rows > 0 ? bias_groups(rows) : 0; }
+
 extern "C" int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride, int act, const void* pre, void* dx,
                                float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
-  BG_REQUIRE(dy && dbias, "bg_bias_act_bwd: null dy/dbias");
+  BG_REQUIRE(dy, "bg_bias_act_bwd: null dy");
   BG_REQUIRE(dtype_ok(dtype), "bg_bias_act_bwd: dtype %d", dtype);
   BG_REQUIRE(rows > 0 && rows < (1ll << 31) && C > 0 && C % 4 == 0 && dy_row_stride >= C && dy_row_stride % 4 == 0,
              "bg_bias_act_bwd: rows=%lld C=%d stride=%lld (C and the stride must be multiples of 4)", (long long)rows, C, (long long)dy_row_stride);
@@ -449,8 +516,26 @@ extern "C" int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, i
   else BG_LAUNCH_BA(bf16_t);
 #undef BG_LAUNCH_BA
   BG_CHECK_LAUNCH("bg_bias_act_bwd");
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace, G, C, 0, 0, dbias, (float*)nullptr,
-                     (float*)nullptr);
-  BG_CHECK_LAUNCH("bg_bias_act_bwd(reduce)");
+  if (dbias) {
+    const ReduceItem item{(const float*)workspace, dbias, G, C, C};
+    launch_reduce(&item, 1, st);
+    BG_CHECK_LAUNCH("bg_bias_act_bwd(reduce)");
+  }
+  return BG_OK;
+}
+
+extern "C" int bg_partial_reduce(const bg_reduce_desc* descs, int count, void* stream) {
+  BG_REQUIRE(count >= 0 && (descs || count == 0), "bg_partial_reduce: count=%d", count);
+  if (count == 0) return BG_OK;
+  std::vector<ReduceItem> items((size_t)count);
+  for (int i = 0; i < count; ++i) {
+    const bg_reduce_desc& d = descs[i];
+    BG_REQUIRE(d.partial && d.out && d.groups > 0 && d.n > 0 && d.stride >= d.n, "bg_partial_reduce: descriptor %d: groups=%d n=%d stride=%d", i,
+               d.groups, d.n, d.stride);
+    BG_REQUIRE((((uintptr_t)d.partial) & 3) == 0 && (((uintptr_t)d.out) & 3) == 0, "bg_partial_reduce: descriptor %d: misaligned pointer", i);
+    items[(size_t)i] = ReduceItem{d.partial, d.out, d.groups, d.stride, d.n};
+  }
+  launch_reduce(items.data(), count, (hipStream_t)stream);
+  BG_CHECK_LAUNCH("bg_partial_reduce");
   return BG_OK;
 }

@@ -179,7 +179,24 @@ int bg_neox_qkv_rope_bwd(const void* dq, const void* dk, const void* dv, int dty
  *   act 1 / 2: dx = dy * gelu'(pre) (tanh / erf form), dbias += column sums of dx.
  * C % 4 == 0; LayerNorm: C <= 4096.  The column reductions are deterministic (per-workgroup partials in the
  * workspace, added in a fixed order) and ACCUMULATE into the fp32 gradients.
+ *
+ * Deferred reductions: a backward pass of L blocks holds ~4L such column reductions, each a ~5 us launch that nothing
+ * but the optimizer waits for.  With dgamma == dbeta == NULL (bg_layernorm_bwd; deferred_colsum != 0 asks for the
+ * dx column sums too) or dbias == NULL (bg_bias_act_bwd) the call leaves its partials in the workspace -
+ * [bg_layernorm_bwd_groups(rows)][2C or 3C] as dgamma | dbeta | colsum, [bg_bias_act_bwd_groups(rows)][C] - and the
+ * caller reduces any number of them later with ONE bg_partial_reduce over a descriptor list (out[c] += sum over
+ * g < groups of partial[g * stride + c], c < n; same summation order as the immediate form, bit-identical results;
+ * descriptors whose `out` ranges overlap are applied one after another in list order, in separate launches).
+ * The workspace of a deferred call must stay untouched until that reduction has run.
  */
+typedef struct bg_reduce_desc {
+  const float* partial;
+  float* out;
+  int32_t groups, stride, n, reserved;
+} bg_reduce_desc;
+int bg_partial_reduce(const bg_reduce_desc* descs, int count, void* stream);
+int bg_layernorm_bwd_groups(int64_t rows);
+int bg_bias_act_bwd_groups(int64_t rows);
 int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
                          const float* gamma, const float* beta, float eps,
                          float* x_out, void* y, int y_dtype, float* mean, float* rstd, void* stream);
@@ -187,7 +204,7 @@ size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* dres, int64_t rows, int C,
                      float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta, float* dx_colsum,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     int deferred_colsum, void* workspace, size_t workspace_bytes, void* stream);
 size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C);
 int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride,
                     int act, const void* pre, void* dx, float* dbias,

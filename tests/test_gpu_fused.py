@@ -268,3 +268,71 @@ def test_add_layernorm_with_two_updates(lowp):
     torch.testing.assert_close(x.grad, xr.grad, atol=2e-4, rtol=1e-4)
     assert torch.equal(a.grad, m.grad)
     torch.testing.assert_close(a.grad.float(), ar.grad, **(dict(atol=3e-2, rtol=2 ** -7) if lowp else dict(atol=2e-4, rtol=1e-4)))
+
+
+def test_partial_reduce_batches_descriptors():
+    """bg_partial_reduce through the C-ABI: 230 reductions of ragged shapes (three launches of <= 96 descriptors) against
+    torch column sums; accumulates into `out`.  fp32, fixed summation order: 1e-5 relative to the column's absolute sum."""
+    import ctypes
+    from branchgan import _capi as C
+    g = torch.Generator().manual_seed(3)
+    shapes = [(int(torch.randint(1, 300, (1,), generator=g)), int(torch.randint(1, 900, (1,), generator=g))) for _ in range(230)]
+    parts, outs, want = [], [], []
+    descs = (C.ReduceDesc * len(shapes))()
+    for d, (G, n) in zip(descs, shapes):
+        stride = n + int(torch.randint(0, 9, (1,), generator=g))
+        p = torch.randn(G, stride, generator=g).cuda()
+        o = torch.randn(n, generator=g).cuda()
+        want.append((o + p[:, :n].double().sum(0).float(), p[:, :n].abs().sum(0)))
+        parts.append(p)
+        outs.append(o)
+        d.partial, d.out, d.groups, d.stride, d.n = p.data_ptr(), o.data_ptr(), G, stride, n
+    C.check(C.lib().bg_partial_reduce(descs, len(shapes), C.stream_ptr()), "bg_partial_reduce")
+    torch.cuda.synchronize()
+    for o, (w, mag) in zip(outs, want):
+        assert bool(((o - w).abs() <= 1e-5 * mag + 1e-6).all())
+    # five reductions into ONE output (a LayerNorm shared by five passes) and one into an overlapping slice of it
+    same = torch.zeros(700, device="cuda")
+    ps = [torch.randn(40, 700, generator=g).cuda() for _ in range(6)]
+    d6 = (C.ReduceDesc * 6)()
+    for i, (d, p) in enumerate(zip(d6, ps)):
+        d.partial, d.out, d.groups, d.stride, d.n = p.data_ptr(), same.data_ptr() + (400 if i == 5 else 0), 40, 700, 100 if i == 5 else 700
+    C.check(C.lib().bg_partial_reduce(d6, 6, C.stream_ptr()), "bg_partial_reduce")
+    want6 = sum(p.double().sum(0) for p in ps[:5])
+    want6[100:200] += ps[5][:, :100].double().sum(0)
+    assert torch.allclose(same.double(), want6, atol=1e-4)
+    assert C.lib().bg_partial_reduce(descs, 0, C.stream_ptr()) == 0
+    descs[5].n = descs[5].stride + 1
+    assert C.lib().bg_partial_reduce(descs, len(shapes), C.stream_ptr()) != 0
+    assert b"descriptor 5" in C.lib().bg_last_error()
+
+
+def test_deferred_reductions_match_immediate_ones(monkeypatch):
+    """The column reductions collected until the end of the backward pass (fused._DeferredReductions) give bit-identical
+    gradients to reducing behind every producer, and `backward()` returns with them complete - also when a previous backward
+    pass died half way and left reductions behind."""
+    from branchgan import fused
+    model = _gpt2(hidden=128, heads=4, layers=3)
+    ids = torch.randint(0, 97, (4, 48), device="cuda")
+
+    def run(defer, dtype):
+        monkeypatch.setattr(fused, "DEFER_REDUCTIONS", defer)
+        grads = []
+        for _ in range(2):                       # the second pass accumulates on top of the first
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype is not None):
+                out = model(input_ids=ids, use_cache=True, returnLmLogits=True)
+                (out.logits.float() ** 2).mean().backward()
+            grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        model.zero_grad(set_to_none=True)
+        return grads
+
+    for dtype in (None, torch.bfloat16):
+        now = run(False, dtype)
+        d = fused._deferred_for(ids.device)
+        d.pending.append((0, None, 1, 1, 1))     # what a backward pass that raised would leave: must be dropped, not reduced
+        later = run(True, dtype)
+        assert not d.pending and not d.armed
+        for a, b in zip(now, later):
+            assert set(a) == set(b)
+            for n in a:
+                assert torch.equal(a[n], b[n]), n
