@@ -1,15 +1,40 @@
 #!/usr/bin/env python3
-"""Which lines of branchgan/ launch the small ATen kernels of one eager train step (torch.profiler with stacks)."""
+"""Which lines of branchgan/ issue the small ATen ops of one eager train step: a TorchDispatchMode that books every op under
+the innermost branchgan/ frame of the Python stack (ops of autograd's own backward nodes have none: booked as '<autograd>')."""
 import collections
 import os
 import sys
+import traceback
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "branch-gan_amd"))
 import bench  # noqa: E402
+
+SKIP = ("aten.view", "aten._unsafe_view", "aten.permute", "aten.transpose", "aten.t.", "aten.slice", "aten.select", "aten.expand", "aten.unsqueeze",
+        "aten.squeeze", "aten.detach", "aten.alias", "aten.as_strided", "aten.empty", "aten.reshape", "aten.unflatten", "aten.split", "aten.unbind",
+        "aten.mm.", "aten.addmm", "aten.lift_fresh", "aten.is_", "aten.sym_", "aten.stride", "aten.size", "aten.numel", "aten._local_scalar_dense")
+
+
+class Book(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.ops = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            where = "<autograd>"
+            for fr in reversed(traceback.extract_stack(limit=30)):
+                if "branchgan/" in fr.filename:
+                    where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+                    break
+            shape = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
+            self.ops[(name, where, shape)] += 1
+        return func(*args, **(kwargs or {}))
 
 
 def main():
@@ -26,26 +51,14 @@ def main():
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
-    from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    with Book() as book:
         step(3)
-        torch.cuda.synchronize()
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):
-            continue
-        dev_us = getattr(ev, "self_device_time_total", 0) or 0
-        if dev_us <= 0:
-            continue
-        frame = next((f for f in (ev.stack or []) if "branchgan" in f or "bench.py" in f), "")
-        frame = frame.split("branch-gan_amd/")[-1] + " " + str(ev.input_shapes)
-        agg[(ev.name, frame)][0] += 1
-        agg[(ev.name, frame)][1] += dev_us
-    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-    for (name, frame), (n, us) in rows[:70]:
-        if name in ("aten::mm", "aten::addmm"):
-            continue
-        print(f"{n:4d} {us:9.1f} us  {name:28s} {frame[:110]}")
+    torch.cuda.synchronize()
+    total = 0
+    for (name, where, shape), n in sorted(book.ops.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+        total += n
+        print(f"{n:4d}  {where:22s} {name:34s} {shape}")
+    print("total", total)
 
 
 if __name__ == "__main__":

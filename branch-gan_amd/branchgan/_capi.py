@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbranchgan_hip.so")
 
 BG_F32, BG_BF16 = 0, 1
 MAX_TOPN, MAX_BLOCKED, MAX_SLOTS, MAX_GATHER = 64, 8, 64, 80
+MAX_RANKS = 8
 
 c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 c_f64 = ctypes.c_double
@@ -54,6 +55,7 @@ SIGNATURES = {
     "bg_topp_select": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_softmax_stats_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_softmax_stats_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "bg_rank_stats": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, ctypes.POINTER(c_i32), c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_branch_attn_fwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_branch_attn_bwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),

@@ -71,6 +71,34 @@ class LMConfig:
                         resid_pdrop=g("resid_pdrop", default=0.0), embd_pdrop=g("embd_pdrop", default=0.0))
 
 
+    def to_dict(self):
+        """HuggingFace key names of the family (what `config.to_json_file` of the reference's GPTNeoXConfig / GPT2Config
+        writes for these fields), so a `Generator-Config.json` written here reads back there and vice versa."""
+        if self.model_type == "gpt_neox":
+            return dict(model_type="gpt_neox", vocab_size=self.vocab_size, hidden_size=self.hidden_size, num_hidden_layers=self.num_hidden_layers,
+                        num_attention_heads=self.num_attention_heads, max_position_embeddings=self.max_position_embeddings,
+                        intermediate_size=self.intermediate_size, rotary_pct=self.rotary_pct, rotary_emb_base=self.rotary_emb_base,
+                        layer_norm_eps=self.layer_norm_eps, use_parallel_residual=self.use_parallel_residual,
+                        initializer_range=self.initializer_range, attention_dropout=self.attn_pdrop, hidden_dropout=self.resid_pdrop)
+        return dict(model_type="gpt2", vocab_size=self.vocab_size, n_embd=self.hidden_size, n_layer=self.num_hidden_layers,
+                    n_head=self.num_attention_heads, n_positions=self.max_position_embeddings, n_inner=self.intermediate_size,
+                    layer_norm_epsilon=self.layer_norm_eps, scale_attn_weights=self.scale_attn_weights,
+                    scale_attn_by_inverse_layer_idx=self.scale_attn_by_inverse_layer_idx, initializer_range=self.initializer_range,
+                    attn_pdrop=self.attn_pdrop, resid_pdrop=self.resid_pdrop, embd_pdrop=self.embd_pdrop)
+
+    def to_json_file(self, path):
+        import json
+        with open(path, "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+    @staticmethod
+    def from_json_file(path):
+        import json
+        import types
+        with open(path) as f:
+            return LMConfig.from_any(types.SimpleNamespace(**json.load(f)))
+
+
 # public model-card dims (SURVEY.md §8 header); dropout 0 as in every parity / benchmark run
 PRESETS = {
     "gpt2-small": LMConfig("gpt2", 50257, 768, 12, 12, 1024),

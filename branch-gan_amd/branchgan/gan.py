@@ -6,7 +6,7 @@ import torch
 
 from . import losses as Losses
 from . import tree as MultiStepPrediction
-from .configs import ReinforcementLearningConfig
+from .configs import LMConfig, ReinforcementLearningConfig
 from .models import NonResidualDiscriminatorWithDualValueHeads, NonResidualGenerator, strip_reference_buffers
 
 
@@ -22,6 +22,7 @@ class GannSetup(torch.nn.Module):
             raise NotImplementedError("generator/discriminator on two devices is out of scope (288 GB per MI355X; SURVEY §2 #13)")
         self.generator = NonResidualGenerator(generatorConfig)
         self.discriminator = NonResidualDiscriminatorWithDualValueHeads(discriminatorConfig)
+        self.generatorConfig, self.discriminatorConfig = LMConfig.from_any(generatorConfig), LMConfig.from_any(discriminatorConfig)
         self.generatorMleLossWeight, self.generatorRlLossWeight = mleLossWeight, rlLossWeight
         self.discValueHeadLossWeight, self.discPredLossWeight = discValueHeadLossWeight, discPredLossWeight
         self.samplingConf = samplingConf

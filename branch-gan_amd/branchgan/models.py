@@ -267,6 +267,26 @@ def strip_reference_buffers(state_dict):
     return out
 
 
+def reference_buffers(module):
+    """The persistent mask buffers a reference checkpoint of `module` would carry next to its parameters:
+    per GPT-2 attention `bias` (causal lower triangle), `self_bias` (all ones) - uint8 (1, 1, P, P) - and `masked_bias`
+    (-1e4); per NeoX attention `self_bias`.  This build evaluates the masks arithmetically and never stores them; they are
+    regenerated only to write a checkpoint a strict reference-side `load_state_dict` accepts."""
+    out = {}
+    sd = module.state_dict()
+    for k, v in sd.items():
+        if k.endswith(".attn.c_attn.weight"):
+            prefix, P = k[:-len("c_attn.weight")], sd[next(n for n in sd if n.endswith("wpe.weight"))].shape[0]
+            out[prefix + "bias"] = torch.tril(torch.ones((P, P), dtype=torch.uint8)).view(1, 1, P, P)
+            out[prefix + "self_bias"] = torch.ones((1, 1, P, P), dtype=torch.uint8)
+            out[prefix + "masked_bias"] = torch.tensor(-1e4)
+        elif k.endswith(".attention.query_key_value.weight"):
+            cfg = next(m.config for m in module.modules() if isinstance(getattr(m, "config", None), LMConfig))
+            P = cfg.max_position_embeddings
+            out[k[:-len("query_key_value.weight")] + "self_bias"] = torch.ones((1, 1, P, P), dtype=torch.uint8)
+    return out
+
+
 class _LMBase(nn.Module):
     def _init_weights(self, std):
         for m in self.modules():

@@ -149,6 +149,36 @@ class _SoftmaxStats(torch.autograd.Function):
         return dx.view(ctx.in_shape), None
 
 
+def rank_stats(x, labels=None, ranks=(), entropy_eps=1e-8):
+    """bg_rank_stats.  x (..., V) fp32; labels (...) int64 or None; ranks: up to 8 ints >= 1.  -> dict of per-row tensors shaped
+    like x without its last dim: 'label_value', 'placement' (int64; both only with labels), 'min', 'max', 'entropy', and
+    'top_mass' (..., len(ranks)) = the sum of the r largest values of each row."""
+    C.require_cuda(x, labels)
+    if x.dtype != torch.float32:
+        raise TypeError("rank_stats: fp32 probabilities only")
+    lead = x.shape[:-1]
+    x2 = _rows_2d(x)
+    rows, V = x2.shape
+    dev = x.device
+    ranks = [int(r) for r in ranks]
+    if len(ranks) > C.MAX_RANKS or any(r < 1 for r in ranks):
+        raise ValueError(f"rank_stats: at most {C.MAX_RANKS} ranks, each >= 1")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    out = {'min': f32(rows), 'max': f32(rows), 'entropy': f32(rows)}
+    lab = None
+    if labels is not None:
+        lab = labels.reshape(rows).contiguous().to(torch.int64)
+        out['label_value'], out['placement'] = f32(rows), torch.empty(rows, dtype=torch.int64, device=dev)
+    if ranks:
+        out['top_mass'] = f32(rows, len(ranks))
+    rk = (ctypes.c_int32 * max(len(ranks), 1))(*ranks)
+    with _timed("rank_stats"):
+        C.check(C.lib().bg_rank_stats(C.ptr(x2), rows, V, x2.stride(0), C.ptr(lab), rk, len(ranks), float(entropy_eps),
+                                      C.ptr(out.get('label_value')), C.ptr(out.get('placement')), C.ptr(out['min']), C.ptr(out['max']),
+                                      C.ptr(out['entropy']), C.ptr(out.get('top_mass')), C.stream_ptr()), "bg_rank_stats")
+    return {k: v.view(*lead, *v.shape[1:]) for k, v in out.items()}
+
+
 def softmax_stats(logits, ids):
     """-> (lse (...,), logp (..., n_ids)): log-sum-exp over the vocabulary and log-softmax at `ids` (id < 0: 0)."""
     return _SoftmaxStats.apply(logits, ids)

@@ -1,0 +1,255 @@
+// Per-row rank statistics over the vocabulary - the (rows, V) work of the evaluation metrics, without a sort.
+//
+// The reference sorts every row of the (B, S, V) probability tensor three times per evaluation batch
+// (Training/Metrics/GeneratorMetrics.py:24-26 `_calcRankProbMasses`: full sort, then sums of the r largest for r up to 1024;
+// :29-50 `_calculateInputIDsPlacementMetric`: full argsort, a (B, S, V) one-hot of the label, a (B, S, V) arange; :64-66,
+// 109-111 label gather, row min / max) and Training/Utils.py:20-21 adds the entropy.  See include/branchgan.h: bg_rank_stats.
+//
+// One 512-thread workgroup per row.  Pass 1 streams the row from HBM once (16-byte loads) for everything that needs no order
+// - label value, the label's position in a stable descending sort (a count), min, max, entropy - and for the first level of
+// an MSD radix select on the order-preserving integer image of the floats (11 + 11 + 10 bits).  Passes 2 and 3 (row now in
+// L2) refine the bucket of each requested rank until the exact r-th largest value is known; pass 4 sums what lies above it.
+// Histogram counters are LDS atomics on integers (exact, order-free); every floating-point sum is a fixed-order tree, so
+// results are bit-reproducible.  HBM-bound: algorithmic bytes = one read of the row.
+#include "common.h"
+
+namespace bg {
+
+constexpr int RS_THREADS = 512;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_BINS = 2048;      // 11-bit digits (the last level uses 1024 of them)
+
+struct RankStatsArgs {
+  const float* x;
+  const int64_t* labels;
+  int64_t V, stride;
+  int n_ranks;
+  int ranks[BG_MAX_RANKS];
+  float eps;
+  float *label_value, *row_min, *row_max, *entropy, *top_mass;
+  int64_t* placement;
+};
+
+// ascending unsigned order == ascending float order (-0 and +0 share a key, as they compare equal; NaNs with the sign bit
+// clear sort above +inf)
+__device__ __forceinline__ uint32_t order_key(float v) {
+  uint32_t u = __float_as_uint(v);
+  u = (u == 0x80000000u) ? 0u : u;
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// f(value, index) over the row: aligned 16-byte loads, scalar head / tail (V and the row stride need not be multiples of 4)
+template <typename F>
+__device__ __forceinline__ void row_foreach(const float* x, int64_t V, F f) {
+  const int mis = (int)((((uintptr_t)x) & 15) / sizeof(float));
+  for (int64_t cb = -mis; cb < V; cb += RS_THREADS * 4) {
+    const int64_t i0 = cb + (int64_t)threadIdx.x * 4;
+    if (i0 >= 0 && i0 + 4 <= V) {
+      const f32x4 raw = *(const f32x4*)(x + i0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f(raw[j], i0 + j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j >= 0 && i0 + j < V) f(x[i0 + j], i0 + j);
+    }
+  }
+}
+
+// fixed-order block reductions: lanes by xor-shuffle, then the 8 wave results in wave order; result in every thread
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, T* scratch, Op op) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < RS_WAVES; ++w) r = op(r, scratch[w]);
+  return r;
+}
+
+// The bin holding the r-th largest element of a histogram (r >= 1, r <= its total) and the count in the bins above it.
+// Every thread owns `PER` consecutive bins; inclusive prefix sums over threads give each thread the count above its bins.
+template <int PER>
+__device__ __forceinline__ void find_rank(const uint32_t* hist, uint32_t r, uint32_t* wave_tot, uint32_t* out /* [2] */) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t h[PER], tot = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { h[j] = hist[t * PER + j]; tot += h[j]; }
+  uint32_t inc = tot;                                   // inclusive prefix over lanes, then over waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < RS_WAVES; ++w) {
+    if (w < wave) before += wave_tot[w];
+    total += wave_tot[w];
+  }
+  uint32_t above = total - (before + inc);              // elements in bins of higher threads
+#pragma unroll
+  for (int j = PER - 1; j >= 0; --j) {
+    if (above < r && r <= above + h[j]) { out[0] = (uint32_t)(t * PER + j); out[1] = above; }
+    above += h[j];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a) {
+  // [0, 16384): histograms (level 1: 4 lane-interleaved copies of 2048 bins; levels 2, 3: one histogram per rank)
+  __shared__ uint32_t lds[BG_MAX_RANKS * RS_BINS + 64];
+  uint32_t* hist = lds;
+  uint32_t* scratch = lds + BG_MAX_RANKS * RS_BINS;     // 8 words of reduction scratch, 8 of wave totals, 2 per rank of results
+  uint32_t* wave_tot = scratch + 8;
+  uint32_t* sel = scratch + 16;                         // sel[2 i] = bin, sel[2 i + 1] = count above, for rank i
+
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float* x = a.x + row * a.stride;
+  const int64_t V = a.V;
+  const int64_t label = a.labels ? a.labels[row] : -1;
+  const bool has_label = label >= 0 && label < V;
+  const float xl = has_label ? x[label] : 0.f;
+  const uint32_t kl = order_key(xl);
+  const int nr = a.n_ranks;
+
+  for (int i = t; i < 4 * RS_BINS; i += RS_THREADS) hist[i] = 0;
+  __syncthreads();
+
+  // ---- pass 1 ---------------------------------------------------------------------------------------------------------
+  float mn = INFINITY, mx = -INFINITY, ent = 0.f;
+  uint32_t n_gt = 0, n_eq_before = 0;
+  uint32_t* my_hist = hist + (t & 3) * RS_BINS;
+  const float eps = a.eps;
+  row_foreach(x, V, [&](float v, int64_t j) {
+    const uint32_t k = order_key(v);
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    ent += v * logf(v + eps);
+    n_gt += k > kl;
+    n_eq_before += (k == kl) & (j < label);
+    if (nr > 0) atomicAdd(&my_hist[k >> 21], 1u);
+  });
+  mn = block_reduce(mn, (float*)scratch, [](float p, float q) { return fminf(p, q); });
+  mx = block_reduce(mx, (float*)scratch, [](float p, float q) { return fmaxf(p, q); });
+  ent = block_reduce(ent, (float*)scratch, [](float p, float q) { return p + q; });
+  n_gt = block_reduce(n_gt, scratch, [](uint32_t p, uint32_t q) { return p + q; });
+  n_eq_before = block_reduce(n_eq_before, scratch, [](uint32_t p, uint32_t q) { return p + q; });
+  if (t == 0) {
+    if (a.label_value) a.label_value[row] = has_label ? xl : __uint_as_float(0x7FC00000u);
+    if (a.placement) a.placement[row] = has_label ? (int64_t)n_gt + (int64_t)n_eq_before : -1;
+    if (a.row_min) a.row_min[row] = mn;
+    if (a.row_max) a.row_max[row] = mx;
+    if (a.entropy) a.entropy[row] = -ent;
+  }
+  if (nr == 0) return;
+
+  // ---- radix select of the r-th largest value for every requested rank --------------------------------------------------
+  __syncthreads();
+  for (int i = t; i < RS_BINS; i += RS_THREADS) hist[i] += hist[RS_BINS + i] + hist[2 * RS_BINS + i] + hist[3 * RS_BINS + i];
+  __syncthreads();
+  uint32_t want[BG_MAX_RANKS], prefix[BG_MAX_RANKS], above[BG_MAX_RANKS];      // uniform across the block
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) {
+      want[i] = (uint32_t)(a.ranks[i] < V ? a.ranks[i] : V);
+      find_rank<RS_BINS / RS_THREADS>(hist, want[i], wave_tot, sel + 2 * i);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) { prefix[i] = sel[2 * i]; above[i] = sel[2 * i + 1]; }
+  }
+  __syncthreads();
+
+  // level 2: the next 11 bits among the elements whose top 11 bits equal the rank's bucket
+  for (int i = t; i < nr * RS_BINS; i += RS_THREADS) hist[i] = 0;
+  __syncthreads();
+  row_foreach(x, V, [&](float v, int64_t) {
+    const uint32_t k = order_key(v);
+#pragma unroll
+    for (int i = 0; i < BG_MAX_RANKS; ++i)
+      if (i < nr && (k >> 21) == prefix[i]) atomicAdd(&hist[i * RS_BINS + ((k >> 10) & 0x7FFu)], 1u);
+  });
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i)
+    if (i < nr) find_rank<RS_BINS / RS_THREADS>(hist + i * RS_BINS, want[i] - above[i], wave_tot, sel + 2 * i);
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) { prefix[i] = (prefix[i] << 11) | sel[2 * i]; above[i] += sel[2 * i + 1]; }
+  }
+  __syncthreads();
+
+  // level 3: the last 10 bits
+  for (int i = t; i < nr * RS_BINS; i += RS_THREADS) hist[i] = 0;
+  __syncthreads();
+  row_foreach(x, V, [&](float v, int64_t) {
+    const uint32_t k = order_key(v);
+#pragma unroll
+    for (int i = 0; i < BG_MAX_RANKS; ++i)
+      if (i < nr && (k >> 10) == prefix[i]) atomicAdd(&hist[i * RS_BINS + (k & 0x3FFu)], 1u);
+  });
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i)
+    if (i < nr) find_rank<1024 / RS_THREADS>(hist + i * RS_BINS, want[i] - above[i], wave_tot, sel + 2 * i);
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) { prefix[i] = (prefix[i] << 10) | sel[2 * i]; above[i] += sel[2 * i + 1]; }      // prefix = key of the r-th largest
+  }
+
+  // ---- pass 4: the mass above each threshold; the threshold value itself fills the remaining (r - above) places -------------
+  float acc[BG_MAX_RANKS];
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) acc[i] = 0.f;
+  row_foreach(x, V, [&](float v, int64_t) {
+    const uint32_t k = order_key(v);
+#pragma unroll
+    for (int i = 0; i < BG_MAX_RANKS; ++i)
+      if (i < nr && k > prefix[i]) acc[i] += v;
+  });
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) {
+      const float s = block_reduce(acc[i], (float*)scratch, [](float p, float q) { return p + q; });
+      if (t == 0) a.top_mass[row * nr + i] = s + (float)(want[i] - above[i]) * key_value(prefix[i]);
+    }
+  }
+}
+
+}  // namespace bg
+
+using namespace bg;
+
+extern "C" int bg_rank_stats(const float* x, int64_t rows, int64_t V, int64_t row_stride, const int64_t* labels, const int32_t* ranks,
+                             int n_ranks, float entropy_eps, float* label_value, int64_t* placement, float* row_min, float* row_max,
+                             float* entropy, float* top_mass, void* stream) {
+  BG_REQUIRE(x, "bg_rank_stats: null x");
+  BG_REQUIRE(rows > 0 && rows < (1ll << 31) && V > 0 && V < (1ll << 31) && row_stride >= V, "bg_rank_stats: rows=%lld V=%lld stride=%lld",
+             (long long)rows, (long long)V, (long long)row_stride);
+  BG_REQUIRE((((uintptr_t)x) & 3) == 0, "bg_rank_stats: misaligned x");
+  BG_REQUIRE(n_ranks >= 0 && n_ranks <= BG_MAX_RANKS && (n_ranks == 0 || (ranks && top_mass)), "bg_rank_stats: n_ranks=%d (at most %d, with ranks and top_mass)",
+             n_ranks, BG_MAX_RANKS);
+  BG_REQUIRE(!placement || labels, "bg_rank_stats: placement without labels");
+  RankStatsArgs a{};
+  a.x = x; a.labels = labels; a.V = V; a.stride = row_stride; a.n_ranks = n_ranks; a.eps = entropy_eps;
+  for (int i = 0; i < n_ranks; ++i) {
+    BG_REQUIRE(ranks[i] >= 1, "bg_rank_stats: ranks[%d]=%d must be at least 1", i, ranks[i]);
+    a.ranks[i] = ranks[i];
+  }
+  a.label_value = label_value; a.placement = placement; a.row_min = row_min; a.row_max = row_max; a.entropy = entropy; a.top_mass = top_mass;
+  hipLaunchKernelGGL(rank_stats_kernel, dim3((unsigned)rows), dim3(RS_THREADS), 0, (hipStream_t)stream, a);
+  BG_CHECK_LAUNCH("bg_rank_stats");
+  return BG_OK;
+}

@@ -34,6 +34,7 @@ extern "C" {
 #define BG_MAX_TOPN 64      /* samples per row */
 #define BG_MAX_BLOCKED 8    /* blocked ids per row */
 #define BG_MAX_SLOTS 64     /* branch KV slots (tree nodes incl. self) one call can see */
+#define BG_MAX_RANKS 8      /* rank thresholds per bg_rank_stats call */
 
 const char* bg_last_error(void);
 int bg_version(void);
@@ -90,6 +91,26 @@ int bg_softmax_stats_bwd(const void* logits, int dtype, int64_t rows, int64_t V,
                          const int64_t* ids, int n_ids, const float* lse,
                          const float* g_lse, const float* g_logp,
                          void* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-row rank statistics over the vocabulary: the (rows, V) work of the evaluation metrics in one kernel, no sort.
+ * Replaces Training/Metrics/GeneratorMetrics.py:24-26 (_calcRankProbMasses: full sort + prefix sums), :29-50
+ * (_calculateInputIDsPlacementMetric: full argsort + (B,S,V) one-hot), :64-66 / :109-111 (label gather, row min / max)
+ * and Training/Utils.py:20-21 (entropy).  x fp32 [rows][V] (row stride in elements), any values (NaNs order above +inf).
+ *   label_value[r] = x[r][labels[r]]            (labels[r] outside [0, V): NaN, placement -1; labels may be NULL)
+ *   placement[r]   = position of the label in a STABLE descending sort of the row
+ *                  = #{j : x[r][j] > x[r][l]} + #{j < l : x[r][j] == x[r][l]}   (torch.argsort is not stable: on tied
+ *                    values the reference's position is any of the tied ones)
+ *   row_min, row_max;  entropy[r] = -sum_j x * log(x + entropy_eps)
+ *   top_mass[r][i] = sum of the min(ranks[i], V) largest values of the row, exact (an MSD radix select finds the
+ *                    ranks[i]-th largest value; ties at it are counted as often as they fit)
+ * ranks: HOST array of n_ranks <= BG_MAX_RANKS values >= 1.  Every output pointer is optional (NULL: not written),
+ * top_mass is required when n_ranks > 0.  Deterministic (integer histograms, fixed-order sums).
+ */
+int bg_rank_stats(const float* x, int64_t rows, int64_t V, int64_t row_stride, const int64_t* labels,
+                  const int32_t* ranks, int n_ranks, float entropy_eps,
+                  float* label_value, int64_t* placement, float* row_min, float* row_max, float* entropy,
+                  float* top_mass, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Branch ("non-residual") attention, forward and backward, with the mask computed arithmetically.

@@ -372,8 +372,125 @@ def g3_g5(family, tag, rules_spec, seed, sparse, B=2, S=12):
     save(f"g35_{tag}", **out)
 
 
+def g6_schedules():
+    """Update / learning-rate / checkpoint schedules: decisions of the reference's own classes on fixed
+    (step, epoch) grids -> g6_schedules.json.  Training/Utils.py imports wandb (absent here): an empty stand-in module is
+    registered for the import only - nothing of it is called."""
+    import contextlib
+    import io
+    import json
+    import types
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    from Training import GanUpdateSchedule as GUS
+    from Training import Optimizers as RO
+    from Training import Utils as RU
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    points = [[s, e] for e in range(3) for s in (0, 1, 2, 3, 4, 5, 6, 7, 10, 99, 100, 101, 1000)]
+    upd = []
+    for cls, args in (("AlwaysUpdateSchedule", []), ("NeverUpdateSchedule", []), ("OnlyUpdateDisc", []), ("OnlyUpdateGen", []),
+                      ("AlternateSequence", []), ("AlternateSequence", [3]), ("AlternateOverEpochsUpdateSchedule", []),
+                      ("GeneratorSlowStart", [100]), ("GeneratorSlowStart", [0])):
+        sched = getattr(GUS, cls)(*args)
+        upd.append(dict(cls=cls, args=args, repr=repr(sched), saves=[sched.saveGen, sched.saveDisc], points=points,
+                        decisions=[list(sched.getGenDiscUpdates(s, e, None, None)) for s, e in points]))
+    freeze = []
+    for base_lr, kw, steps in ((0.5, dict(zero_steps=3, warmup_steps=5, lr_start=1e-5, lr_end=1e-3), 12),
+                               (1e-4, dict(zero_steps=0, warmup_steps=4, lr_start=0.0, lr_end=2e-4, step_size_down=7), 8),
+                               (1e-4, dict(zero_steps=2, warmup_steps=1, lr_start=5e-5, lr_end=1e-5), 6)):
+        p = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.SGD([p], lr=base_lr)
+        sch = RO.FreezeLRSchedule(opt, **kw)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(steps):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        freeze.append(dict(base_lr=base_lr, kwargs=kw, steps=steps, lrs=lrs))
+    created = []
+    for args, accum, n_batches, epochs, steps in ((dict(base_lr=1e-5, max_lr=1e-3, step_size_up=6), 2, 20, 2, 24),
+                                                  (dict(base_lr=1e-4, max_lr=5e-4), 1, 10, 1, 12)):
+        p = torch.nn.Parameter(torch.zeros(3))
+        opt = torch.optim.SGD([p], lr=0.1, momentum=0.9)
+        with quiet:
+            sch = RO._createScheduler(torch.optim.lr_scheduler.CyclicLR, dict(args), opt, accum, [0] * n_batches, epochs)
+        lrs = []
+        for _ in range(steps):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        created.append(dict(args=args, gradAccum=accum, stepsPerEpoch=n_batches, epochs=epochs, steps=steps, lrs=lrs))
+    trackers = []
+    for args, kw, epochs, batches in (([0.25, 40], {}, 3, 40), ([0.3, 10], dict(maxEpoch=None, epochSaveFrequency=2), 4, 10),
+                                      ([None, 10], {}, 2, 10), ([0.5, 8], dict(enabled=False), 2, 8)):
+        tr = RU.ModelSaveFrequencyTracker(*args, **kw)
+        events = []
+        with quiet:
+            for epoch in range(epochs):
+                tr.initEpoch()
+                for b in range(batches):
+                    due, name = tr.shouldModelBeSaved(b, epoch)
+                    if due:
+                        events.append([epoch, b, name])
+                events.append([epoch, "end", bool(tr.shouldModelBeSavedAtThisEpoch(epoch + 1))])
+        trackers.append(dict(args=args, kwargs=kw, epochs=epochs, batches=batches, events=events))
+    path = os.path.join(OUT, "g6_schedules.json")
+    with open(path, "w") as f:
+        json.dump(dict(update_schedules=upd, freeze_lr=freeze, create_scheduler=created, save_tracker=trackers), f, indent=1)
+    print("wrote", path)
+
+
+def g7_metrics():
+    """Evaluation metrics: the reference's Training/Metrics functions on random inputs -> g7_metrics.npz.
+    Inputs and every returned value are stored; V = 97 exercises rank thresholds beyond the vocabulary."""
+    import types
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    from Training import Utils as RU
+    from Training.Metrics import DiscriminatorMetrics as DM
+    from Training.Metrics import GeneratorMetrics as GM
+    from Training.Metrics import MetricUtils as MU
+    out = {}
+    for tag, (B, S, V, N) in {"a": (2, 12, 1031, 3), "b": (3, 9, 97, 2), "c": (1, 6, 2500, 4)}.items():
+        g = torch.Generator().manual_seed(700 + V)
+        probs = torch.softmax(3 * torch.randn(B, S, V, generator=g), dim=-1)
+        ids = torch.randint(0, V, (B, S), generator=g)
+        head = torch.scatter(probs[:, :-1], dim=-1, index=ids[:, 1:].unsqueeze(-1), value=0)
+        masked = torch.cat((head, probs[:, -1:]), dim=1)
+        d_in = torch.rand(B, S, generator=g)
+        d_alt = torch.rand(B, N, S, generator=g)
+        heads = {'txtInputPreds': torch.rand(B, S, 1, generator=g), 'txtAlterationsPreds': torch.rand(B, S, 1, generator=g),
+                 'altInputPreds': torch.rand(N, B, S, 1, generator=g), 'altAlterationsPreds': torch.rand(N, B, S, 1, generator=g)}
+        adv = torch.randn(B, 1 + N, S - 1, generator=g)
+        out.update({f"{tag}::in::probs": probs, f"{tag}::in::ids": ids, f"{tag}::in::masked": masked, f"{tag}::in::d_in": d_in,
+                    f"{tag}::in::d_alt": d_alt, f"{tag}::in::adv": adv})
+        out.update({f"{tag}::in::heads::{k}": v for k, v in heads.items()})
+        ent = RU.entropy(probs)
+        out[f"{tag}::entropy"] = ent
+        for k, v in GM.calculateGeneratorMetrics(ids, probs, masked, d_in, d_alt).items():
+            out[f"{tag}::gen::{k}"] = v
+        for k, v in GM.calculateGeneratorMetricsNoDiscriminator(ids, probs, ent).items():
+            out[f"{tag}::gen_nodisc::{k}"] = v
+        for k, v in DM.calcDiscriminatorMetrics(d_in, d_alt, {'DiscValueHeads': heads}).items():
+            out[f"{tag}::disc::{k}"] = v
+        a, b = DM.calcAdvantageRatios(adv)
+        out[f"{tag}::adv_ratio"] = torch.stack((a, b))
+        out[f"{tag}::mle_probs"] = MU.mleLossFromProbs(ids, probs)
+        logits = torch.log(probs)
+        out[f"{tag}::mle_logits"] = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, V), ids[:, 1:].reshape(-1))
+        # placements where the label's probability is unique in its row (elsewhere an unstable argsort may put it anywhere in the tie)
+        lab = torch.gather(probs[:, :-1], -1, ids[:, 1:].unsqueeze(-1))
+        out[f"{tag}::label_unique"] = (probs[:, :-1] == lab).sum(-1) == 1
+        out[f"{tag}::placements"] = GM._calculateInputIDsPlacementMetric(ids, probs)[0]
+    save("g7_metrics", **out)
+
+
 def main():
     torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
+    if sys.argv[1:] == ["g6"]:
+        return g6_schedules()
+    if sys.argv[1:] == ["g7"]:
+        return g7_metrics()
+    g6_schedules()
+    g7_metrics()
     g1_attention()
     g2_sampling()
     g4_losses()
