@@ -104,6 +104,24 @@ class GannSetup(torch.nn.Module):
                 raise Exception("Generator loss {} is NaN".format(keys[int(bad.float().argmax())]))
         return discLosses, genLosses, genData, discData, fpd
 
+    def trainForwardPass(self, inputIDs, samplingConf, numNegativeUpdateSamples=1, **kwargs):
+        """GanSetup.py:260-285: the forward pass plus the evaluation metrics of both models (branchgan.metrics; the (B, S, V)
+        work is two kernels, no sort).  As in the reference the metrics compare text and alteration scores position by
+        position, so the sampling config must branch at every position (numSampleSequences=None)."""
+        from . import metrics
+        discLosses, genLosses, genData, discData, fpd = self._internalTrainForwardPass(inputIDs, samplingConf, numNegativeUpdateSamples, **kwargs)
+        _, genProbs, maskedProbs = genData
+        discInputPreds, discAlterationScores, _, _ = discData
+        discInputScores = discInputPreds.prediction
+        if discAlterationScores.shape[-1] != discInputScores.shape[-1]:
+            raise ValueError("trainForwardPass: the metrics need a branch at every text position (K == S): evaluate with "
+                             "SamplingConfig(numSampleSequences=None); got K={} S={}".format(discAlterationScores.shape[-1], discInputScores.shape[-1]))
+        ids = inputIDs.to(self.generatorDevice)
+        with torch.no_grad():
+            generatorMetrics = metrics.calculateGeneratorMetrics(ids, genProbs, maskedProbs, discInputScores.detach(), discAlterationScores.detach())
+            discMetrics = metrics.calcDiscriminatorMetrics(discInputScores.detach(), discAlterationScores.detach(), fpd)
+        return discLosses, genLosses, discMetrics, generatorMetrics
+
     def trainForwardPassNoMetrics(self, inputIDs, samplingConf, numNegativeUpdateSamples=1, **kwargs):
         discLosses, genLosses, *_ = self._internalTrainForwardPass(inputIDs, samplingConf, numNegativeUpdateSamples, **kwargs)
         return discLosses, genLosses

@@ -218,19 +218,133 @@ def train_step(model, inputIDs, sampleConf, generatorOptim, discriminatorOptim, 
     return discLosses, genLosses
 
 
-def efficentTrainingLoop(model, trainDataset, numEpochs, generatorOptim, discriminatorOptim, trainingSamplingConf, numUpdateSamples,
-                         depthSchedule=None, reinforcementLearningConfig=None, log_every=0, rank=0, **kwargs):
-    """TrainingLoop.py:107-192 without evaluation / checkpointing (out of scope): epochs over an iterable of (B, S) id batches."""
-    stepCounter, history = 0, []
-    for epoch in range(int(numEpochs)):
+def _appendToCollectedData(collected, new, ignoreTrackingKeys=()):
+    """TrainingLoop.py:9-22: lists are extended, ints and 0-d tensors appended as Python numbers, other tensors as numpy."""
+    for k, v in new.items():
+        if k in ignoreTrackingKeys:
+            continue
+        slot = collected.setdefault(k, [])
+        if isinstance(v, list):
+            slot.extend(v)
+        elif isinstance(v, (int, float)):
+            slot.append(v)
+        elif v.dim() >= 1:
+            slot.append(v.detach().float().cpu().numpy() if v.is_floating_point() else v.detach().cpu().numpy())
+        else:
+            slot.append(v.item())
+
+
+def forwardPass(model, inData, sampleConf, numUpdateSamples, stepCounter=None, collectedGenData=None, collectedDiscData=None,
+                updateGenerator=False, updateDiscriminator=False, generatorOptim=None, discriminatorOptim=None, ignoreTrackingKeys=()):
+    """TrainingLoop.py:25-52: one forward pass with metrics; losses are merged into the metric dicts (metrics win on a key
+    clash) and both are appended to the running collections."""
+    discLosses, genLosses, discMetrics, genMetrics = model.trainForwardPass(inData, sampleConf, numUpdateSamples, collectData=True)
+    if updateGenerator:
+        generatorOptim.performUpdateStep(genLosses, stepCounter)
+    if updateDiscriminator:
+        discriminatorOptim.performUpdateStep(discLosses, stepCounter)
+    for origin, target in ((discLosses, discMetrics), (genLosses, genMetrics)):
+        for k, v in origin.items():
+            target.setdefault(k, v)
+    collectedDiscData = {} if collectedDiscData is None else collectedDiscData
+    collectedGenData = {} if collectedGenData is None else collectedGenData
+    _appendToCollectedData(collectedDiscData, discMetrics, ignoreTrackingKeys)
+    _appendToCollectedData(collectedGenData, genMetrics, ignoreTrackingKeys)
+    return collectedDiscData, collectedGenData
+
+
+def validateModel(model, testData, samplingStrategies={}, displayProgress=True):
+    """TrainingLoop.py:83-104: every named sampling strategy over the whole test set, without gradients.
+    -> {name: (collectedDiscData, collectedGenData)}."""
+    if testData is None:
+        return {}
+    results = {}
+    with torch.no_grad():
+        for name, conf in samplingStrategies.items():
+            discData, genData = {}, {}
+            for bIDs in testData:
+                discData, genData = forwardPass(model, bIDs, conf.getNextSampleConf(), numUpdateSamples=1, collectedGenData=genData,
+                                                collectedDiscData=discData)
+                results[name] = (discData, genData)
+    return results
+
+
+def logResults(validationResult, genData, discData, trainDataset, epochCounter, batchCounter, generatorOptim, discriminatorOptim,
+               trainingConf, sink=print):
+    """TrainingLoop.py:55-79: means of everything collected since the last evaluation, handed to `sink` one dict at a time
+    (the reference prints; a logger can be plugged in).  Returns the dicts."""
+    import numpy as np
+    out = []
+
+    def emit(data, prefix):
+        row = {"{}-{}".format(prefix, k): np.mean(v) for k, v in data.items()}
+        out.append(row)
+        sink(row)
+
+    for name, (valDisc, valGen) in validationResult.items():
+        emit(valDisc, 'Val-{}_Discriminator'.format(name))
+        emit(valGen, 'Val-{}_Generator'.format(name))
+    if getattr(discriminatorOptim, 'scheduler', None) is not None:
+        discData['lr'] = discriminatorOptim.scheduler.get_last_lr()[0]
+    if getattr(generatorOptim, 'scheduler', None) is not None:
+        discData['genData'] = generatorOptim.scheduler.get_last_lr()[0]          # the reference files the generator's lr here
+    if trainingConf is not None and getattr(trainingConf, 'depthSchedule', None) is not None:
+        genData['generationDepth'] = trainingConf.depthSchedule.currentDepth
+    emit({'Epoch': epochCounter + (batchCounter / len(trainDataset))}, '')
+    emit(discData, 'Discriminator')
+    emit(genData, 'Generator')
+    return out
+
+
+def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOptim, discriminatorOptim, trainingSamplingConf,
+                         numUpdateSamples, updatesPerEvaluation, validationSamplingConf, doLogData=True, displayProgression=False,
+                         saveModel=True, saveName='SavedModel', genDiscUpdateSchedule=None, datasetConf=None, trainingConf=None,
+                         **kwargs):
+    """TrainingLoop.py:107-192, same arguments: epochs over an iterable of (B, S) id batches; per micro-step the update
+    schedule decides which model steps, the depth schedule how deep the tree is; every `updatesPerEvaluation` steps (first
+    after step 1) the validation strategies run, results are logged and a 'Current' checkpoint is written; further
+    checkpoints by `saveFreq` / `epochSaveFreq` (schedules.ModelSaveFrequencyTracker).  `mainSavePath` (extra keyword) roots
+    the checkpoints.  Returns the log rows."""
+    from . import checkpoint, schedules
+    sched = genDiscUpdateSchedule if genDiscUpdateSchedule is not None else schedules.AlwaysUpdateSchedule()
+    tracker = schedules.ModelSaveFrequencyTracker(kwargs.pop('saveFreq', None), len(trainDataset), enabled=saveModel,
+                                                  epochSaveFrequency=kwargs.pop('epochSaveFreq', None))
+    save_root, sink = kwargs.pop('mainSavePath', ''), kwargs.pop('logSink', print)
+    depthSchedule = getattr(trainingConf, 'depthSchedule', None)
+    rlConf = getattr(trainingConf, 'reinforcementLearningConfig', None)
+
+    def save(marker):
+        checkpoint.saveGannSetup(model, saveName, marker, discriminatorOptim, generatorOptim, mainSavePath=save_root, datasetConf=datasetConf,
+                                 trainingConf=trainingConf, saveGen=sched.saveGen, saveDisc=sched.saveDisc,
+                                 saveOptimizers=getattr(trainingConf, 'saveOptimizers', True))
+
+    stepCounter, epochCounter, log = 0, 0, []
+    for _ in range(int(numEpochs)):
+        discData, genData = {}, {}
+        tracker.initEpoch()
         for i, bIDs in enumerate(trainDataset):
+            updateDisc, updateGen = sched.getGenDiscUpdates(stepCounter, epochCounter, generatorOptim, discriminatorOptim)
             conf = trainingSamplingConf.getNextSampleConf()
             if depthSchedule is not None:
-                depthSchedule.updateSchedule(epoch, i, stepCounter)
+                depthSchedule.updateSchedule(epochCounter, i, stepCounter)
                 conf = depthSchedule.setSampleConfDepth(conf)
-            d, g = train_step(model, bIDs, conf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples,
-                              reinforcementLearningConfig, **kwargs)
+            discLosses, genLosses = train_step(model, bIDs, conf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples, rlConf,
+                                               updateGen=updateGen, updateDisc=updateDisc, **kwargs)
+            _appendToCollectedData(discData, discLosses)
+            _appendToCollectedData(genData, genLosses)
             stepCounter += 1
-            if log_every and rank == 0 and stepCounter % log_every == 0:
-                history.append((stepCounter, float(d['loss']), float(g['loss'])))
-    return history
+            if stepCounter % updatesPerEvaluation == 1:             # == 1: an early first evaluation, as in the reference
+                validationResult = validateModel(model, testData, samplingStrategies=validationSamplingConf, displayProgress=displayProgression)
+                if doLogData:
+                    log.extend(logResults(validationResult, genData, discData, trainDataset, epochCounter, i, generatorOptim, discriminatorOptim,
+                                          trainingConf, sink=sink))
+                discData, genData = {}, {}
+                if saveModel:
+                    save('Current')
+            due, name = tracker.shouldModelBeSaved(i, epochCounter)
+            if saveModel and due:
+                save(name)
+        epochCounter += 1
+        if saveModel and tracker.epochSaveFrequency and tracker.shouldModelBeSavedAtThisEpoch(epochCounter):
+            save("Epoch-{}".format(epochCounter))
+    return log
