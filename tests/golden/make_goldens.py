@@ -483,14 +483,52 @@ def g7_metrics():
     save("g7_metrics", **out)
 
 
+def g8_dataloader():
+    """Dataset streaming: the batch sequence of the reference's PickleBasedDataloader (doShuffle=False) over
+    a small synthetic dataset this script writes into a temporary directory (three files of 10 / 7 / 13 samples, ids that
+    encode file and row), for several (batch size, world, rank, maxNumSamples) and two epochs -> g8_dataloader.json with the
+    dataset itself, so the test can rebuild the files."""
+    import contextlib
+    import io
+    import json
+    import pickle
+    import tempfile
+    from DataManagers import DataUtils
+    files = {"part_a.pkl": 10, "part_b.pkl": 7, "part_c.pkl": 13}
+    data = {name: [[1000 * (fi + 1) + r, r, fi, 7, 8] for r in range(n)] for fi, (name, n) in enumerate(files.items())}
+    cases = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, rows in data.items():
+            with open(os.path.join(tmp, name), "wb") as fp:
+                pickle.dump(rows, fp)
+        with open(os.path.join(tmp, "meta.json"), "w") as fp:
+            json.dump(files, fp)
+        order = [os.path.basename(f) for f in DataUtils.getAllMatchingDatasetFiles(tmp)[0]]
+        for batch, world, rank, cap in ((4, None, None, None), (3, 2, 0, None), (3, 2, 1, None), (2, 3, 2, None), (5, None, None, 18),
+                                        (4, 4, 1, None)):
+            with contextlib.redirect_stdout(io.StringIO()):
+                dl = DataUtils.loadPreTokenizedDataloader(batch, tmp, doShuffle=False, maxNumSamples=cap, ddpWorldSize=world, ddpRank=rank,
+                                                          verbose=False)
+                epochs = [[b.tolist() for b in dl] for _ in range(2)]
+            cases.append(dict(batch=batch, world=world, rank=rank, maxNumSamples=cap, numBatches=len(dl), numSamples=dl.numSamples,
+                              epochs=epochs))
+    path = os.path.join(OUT, "g8_dataloader.json")
+    with open(path, "w") as f:
+        json.dump(dict(files=files, file_order=order, data=data, cases=cases), f)
+    print("wrote", path)
+
+
 def main():
     torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
+    if sys.argv[1:] == ["g8"]:
+        return g8_dataloader()
     if sys.argv[1:] == ["g6"]:
         return g6_schedules()
     if sys.argv[1:] == ["g7"]:
         return g7_metrics()
     g6_schedules()
     g7_metrics()
+    g8_dataloader()
     g1_attention()
     g2_sampling()
     g4_losses()

@@ -94,3 +94,24 @@ def test_update_schedule_freezes_the_generator():
                                   genDiscUpdateSchedule=schedules.OnlyUpdateDisc())
     assert all(torch.equal(v, before_g[k]) for k, v in model.generator.state_dict().items())
     assert any(not torch.equal(v, before_d[k]) for k, v in model.discriminator.state_dict().items())
+
+
+def test_token_stream_prefetch_to_gpu(tmp_path):
+    """The pinned-buffer / side-stream staging hands out the same batches as the CPU stream, in order, over three epochs."""
+    import json
+    from branchgan import data
+    rng = np.random.RandomState(0)
+    files = {}
+    for i, n in enumerate((37, 5, 64)):
+        rng.randint(0, 50257, (n, 128)).astype('<i4').tofile(tmp_path / f"part{i}.ids")
+        files[f"part{i}.ids"] = n
+    with open(tmp_path / "dataset.json", "w") as fp:
+        json.dump({"format": data.FORMAT, "seq_len": 128, "files": files}, fp)
+    for shuffle in (False, True):
+        cpu = data.loadPreTokenizedDataloader(8, str(tmp_path), doShuffle=shuffle, seed=9, ddpWorldSize=2, ddpRank=1)
+        gpu = data.loadPreTokenizedDataloader(8, str(tmp_path), doShuffle=shuffle, seed=9, ddpWorldSize=2, ddpRank=1, device="cuda")
+        assert len(cpu) == len(gpu) == 6
+        for _ in range(3):
+            for a, b in zip(cpu, gpu):
+                assert b.is_cuda and b.dtype == torch.int64 and b.shape == (8, 128)
+                assert torch.equal(a, (b + 0).cpu())             # a kernel on the current stream reads the batch: ordered after the copy
