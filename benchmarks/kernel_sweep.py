@@ -103,6 +103,11 @@ def sampling(rows, V):
         # (bf16 at rows <= 1024: capturing this backward crashed hipGraph instantiation on ROCm 7.2 - timed eagerly instead)
         ms = timeit_graphed(make_bwd) if small and dt == torch.float32 else globals()['timeit'](make_bwd())
         report(f"softmax_stats_bwd rows={rows} V={V} {dt}", ms, 2 * rows * V * es)
+    # evaluation metrics: one read of the probabilities per row (the reference: three full sorts of the same tensor)
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
+    for ranks in ((), (1, 8, 16, 64, 128, 256, 512, 1024)):
+        ms = timeit(lambda: ops.rank_stats(probs, labels, ranks))
+        report(f"rank_stats ranks={len(ranks)} rows={rows} V={V}", ms, rows * V * e)
     # reference op chain on the same GPU for scale (torch.argsort over V = what _topKSampling does)
     sub = probs[:1024]
     ms = globals()['timeit'](lambda: torch.argsort(sub, dim=-1, descending=True)[:, :4], iters=3, warmup=1)
@@ -149,12 +154,23 @@ def attention(B, H, Dh, S, K, depth, dtype):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="all", choices=["all", "sampling", "attention"])
+    ap.add_argument("--what", default="all", choices=["all", "sampling", "attention", "metrics"])
     ap.add_argument("--rows", type=int, default=8192)
     a = ap.parse_args()
     if a.what in ("all", "sampling"):
         sampling(a.rows, 50304)
         sampling(256, 50257)
+    if a.what == "metrics":
+        g = torch.Generator(device="cuda").manual_seed(2)
+        for rows, V in ((a.rows, 50304), (2048, 50257)):
+            probs = torch.softmax(3.0 * torch.randn(rows, V, device="cuda", generator=g), -1)
+            labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
+            for ranks in ((), (1,), (1, 8, 16, 64, 128, 256, 512, 1024)):
+                ms = timeit(lambda: ops.rank_stats(probs, labels, ranks))
+                report(f"rank_stats ranks={len(ranks)} rows={rows} V={V}", ms, rows * V * 4)
+            sub = probs[:512]
+            ms = timeit(lambda: torch.sort(sub, dim=-1, descending=True), iters=3, warmup=1)
+            report(f"[torch] one full sort, rows=512 scaled to {rows} (the reference runs three)", ms * rows / 512, rows * V * 4)
     if a.what in ("all", "attention"):
         attention(8, 12, 64, 256, 32, 4, torch.bfloat16)      # configs[1]
         attention(8, 12, 64, 256, 32, 4, torch.float32)

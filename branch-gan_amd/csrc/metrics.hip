@@ -7,10 +7,12 @@
 //
 // One 512-thread workgroup per row.  Pass 1 streams the row from HBM once (16-byte loads) for everything that needs no order
 // - label value, the label's position in a stable descending sort (a count), min, max, entropy - and for the first level of
-// an MSD radix select on the order-preserving integer image of the floats (11 + 11 + 10 bits).  Passes 2 and 3 (row now in
-// L2) refine the bucket of each requested rank until the exact r-th largest value is known; pass 4 sums what lies above it.
-// Histogram counters are LDS atomics on integers (exact, order-free); every floating-point sum is a fixed-order tree, so
-// results are bit-reproducible.  HBM-bound: algorithmic bytes = one read of the row.
+// an MSD radix select on the order-preserving integer image of the floats (11 + 11 + 10 bits): a 2048-bin histogram that
+// tells which buckets hold the requested ranks.  Pass 2 (row now in L2 / MALL) compacts the keys of those buckets and
+// everything above them into LDS - for next-token distributions little more than the largest requested rank - where they are
+// sorted and prefix-summed.  Rows too flat for that (more than 8192 keys in the selected buckets) take two more radix levels
+// and a summing pass over the row instead.  Histogram counters are LDS atomics on integers (exact, order-free); every
+// floating-point sum runs in a fixed order, so results are bit-reproducible.  HBM-bound: algorithmic bytes = one read of the row.
 #include "common.h"
 
 namespace bg {
@@ -18,6 +20,7 @@ namespace bg {
 constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_BINS = 2048;      // 11-bit digits (the last level uses 1024 of them)
+constexpr int RS_CAND = 8192;      // keys the fast path sorts in LDS
 
 struct RankStatsArgs {
   const float* x;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void find_rank(const uint32_t* hist, uint32_t r, uint
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a) {
-  // [0, 16384): histograms (level 1: 4 lane-interleaved copies of 2048 bins; levels 2, 3: one histogram per rank)
+  // [0, 16384): histograms (level 1: 8 lane-interleaved copies of 2048 bins; levels 2, 3: one histogram per rank)
   __shared__ uint32_t lds[BG_MAX_RANKS * RS_BINS + 64];
   uint32_t* hist = lds;
   uint32_t* scratch = lds + BG_MAX_RANKS * RS_BINS;     // 8 words of reduction scratch, 8 of wave totals, 2 per rank of results
@@ -123,13 +126,13 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   const uint32_t kl = order_key(xl);
   const int nr = a.n_ranks;
 
-  for (int i = t; i < 4 * RS_BINS; i += RS_THREADS) hist[i] = 0;
+  for (int i = t; i < 8 * RS_BINS; i += RS_THREADS) hist[i] = 0;
   __syncthreads();
 
   // ---- pass 1 ---------------------------------------------------------------------------------------------------------
   float mn = INFINITY, mx = -INFINITY, ent = 0.f;
   uint32_t n_gt = 0, n_eq_before = 0;
-  uint32_t* my_hist = hist + (t & 3) * RS_BINS;
+  uint32_t* my_hist = hist + (t & 7) * RS_BINS;      // probabilities crowd into a few exponent bins: spread the same-address atomics
   const float eps = a.eps;
   row_foreach(x, V, [&](float v, int64_t j) {
     const uint32_t k = order_key(v);
@@ -156,7 +159,12 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
 
   // ---- radix select of the r-th largest value for every requested rank --------------------------------------------------
   __syncthreads();
-  for (int i = t; i < RS_BINS; i += RS_THREADS) hist[i] += hist[RS_BINS + i] + hist[2 * RS_BINS + i] + hist[3 * RS_BINS + i];
+  for (int i = t; i < RS_BINS; i += RS_THREADS) {
+    uint32_t c = hist[i];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) c += hist[k * RS_BINS + i];
+    hist[i] = c;
+  }
   __syncthreads();
   uint32_t want[BG_MAX_RANKS], prefix[BG_MAX_RANKS], above[BG_MAX_RANKS];      // uniform across the block
 #pragma unroll
@@ -172,6 +180,67 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   }
   __syncthreads();
 
+  // ---- fast path: everything a rank can need lies in the buckets at and above the lowest selected one.  When those hold at
+  // most RS_CAND keys (for next-token distributions: the requested ranks plus a few hundred), ONE more pass over the row
+  // compacts them into LDS, a bitonic sort orders them, and each top mass is a prefix sum of the sorted keys - in the sorted
+  // order, so the result does not depend on the order the compaction's atomics happened to run in.
+  uint32_t b_min = prefix[0], n_cand = 0;
+#pragma unroll
+  for (int i = 0; i < BG_MAX_RANKS; ++i) {
+    if (i < nr) {
+      b_min = prefix[i] < b_min ? prefix[i] : b_min;
+      const uint32_t c = above[i] + hist[prefix[i]];
+      n_cand = c > n_cand ? c : n_cand;
+    }
+  }
+  __syncthreads();                                      // hist[] was read above and is overwritten below
+  if (n_cand <= RS_CAND) {
+    uint32_t* cand = lds;                               // [0, n_pad) keys; the counter lives behind the scratch words
+    uint32_t* counter = scratch + 40;
+    uint32_t n_pad = 64;
+    while (n_pad < n_cand) n_pad <<= 1;
+    for (uint32_t i = t; i < n_pad; i += RS_THREADS) cand[i] = 0u;                // key 0 sorts below every real value
+    if (t == 0) *counter = 0u;
+    __syncthreads();
+    const int lane = t & 63;
+    row_foreach(x, V, [&](float v, int64_t) {
+      const uint32_t k = order_key(v);
+      const bool take = (k >> 21) >= b_min;
+      const uint64_t m = __ballot(take);                // one counter update per wave instruction, not one per element
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (take) cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+      }
+    });
+    __syncthreads();
+    for (uint32_t size = 2; size <= n_pad; size <<= 1) {                           // bitonic sort, descending
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t i = t; i < (n_pad >> 1); i += RS_THREADS) {
+          const uint32_t lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+          const uint32_t p = cand[lo], q = cand[hi];
+          const bool desc = (lo & size) == 0;
+          if (desc ? p < q : p > q) { cand[lo] = q; cand[hi] = p; }
+        }
+        __syncthreads();
+      }
+    }
+    const uint32_t per = (n_pad + RS_THREADS - 1) / RS_THREADS;                    // thread t sums cand[t * per, (t + 1) * per)
+#pragma unroll
+    for (int i = 0; i < BG_MAX_RANKS; ++i) {
+      if (i < nr) {
+        float s = 0.f;
+        for (uint32_t j = t * per; j < (t + 1) * per && j < want[i]; ++j) s += key_value(cand[j]);
+        s = block_reduce(s, (float*)scratch, [](float p, float q) { return p + q; });
+        if (t == 0) a.top_mass[row * nr + i] = s;
+      }
+    }
+    return;
+  }
+
+  // ---- general path (flat rows: more than RS_CAND keys share the selected buckets): two more radix levels over the row ----------
   // level 2: the next 11 bits among the elements whose top 11 bits equal the rank's bucket
   for (int i = t; i < nr * RS_BINS; i += RS_THREADS) hist[i] = 0;
   __syncthreads();
