@@ -35,7 +35,13 @@ class GannSetup(torch.nn.Module):
 
     def createDiscAlterationLossWeights(self, inputIDs, alternationNodes, K):
         """GanSetup.py:75-92 on the K real columns: 1 where sparseIndex + depth <= S - 1."""
-        pos = torch.stack([n.sparseIndex + n.depth for n in alternationNodes]).to(inputIDs.device)
+        sp = alternationNodes[0].sparseIndex
+        if all(n.sparseIndex is sp for n in alternationNodes) and sp.device == inputIDs.device \
+                and max(n.depth for n in alternationNodes) < MultiStepPrediction._POS_DEPTHS:
+            depths = MultiStepPrediction._depths_tensor(tuple(n.depth for n in alternationNodes), sp.device)
+            pos = MultiStepPrediction._position_table(sp, sp.device).index_select(0, depths)      # one gather for all nodes
+        else:
+            pos = torch.stack([n.sparseIndex + n.depth for n in alternationNodes]).to(inputIDs.device)
         return torch.less_equal(pos, inputIDs.shape[-1] - 1).float()
 
     def _generatorForward(self, inputIDs, samplingConf):

@@ -11,10 +11,11 @@ node fields callers read.  What changed underneath (all exactness-preserving, SU
     reference, :357-362): query (node, k) sees text[0..s_k], its ancestors' column k and itself.
 """
 import contextlib
+import weakref
 
 import torch
 
-from . import ops
+from . import fused, ops
 from . import sampling as SamplingStrategies
 from .models import BranchPast, DiscriminatorOutput
 from .sampling import SamplingTechniques
@@ -125,7 +126,8 @@ class PredictionTreeNode:
         if self.depth == 0:
             pos = torch.arange(self.ids.shape[-1], dtype=torch.int32, device=device)
             return self.ids.to(device), pos.unsqueeze(0).expand(B, -1), None, None
-        pos = (self.sparseIndex.to(device) + self.depth).to(torch.int32).unsqueeze(0).expand(B, -1)
+        pos = (_position_table(self.sparseIndex, device)[self.depth] if self.depth < _POS_DEPTHS
+               else (self.sparseIndex.to(device) + self.depth).to(torch.int32)).unsqueeze(0).expand(B, -1)
         return self.ids.to(device), pos, self.branchPast(ctx_len_of(self.sparseIndex, device)), None
 
     def clearNode(self, clearAll=False, clearAttMask=False, clearSparseIndex=False):
@@ -153,8 +155,27 @@ def _depths_tensor(depths, device):
     return _depth_cache[key]
 
 
+_POS_DEPTHS = 64
+_pos_cache = {}
+
+
+def _position_table(sparseIndex, device):
+    """int32 (64, K): row d = sparseIndex + d - the position ids of depth d and, in row 1, ctx_len.  Built once per sparse
+    index (two launches) instead of an add + cast per tree node and forward; keyed by the tensor's version and by the capture
+    it was made in (memory of a captured graph's pool is not handed to eager code)."""
+    capturing = torch.cuda.is_current_stream_capturing() if sparseIndex.is_cuda else False
+    key = (id(sparseIndex), sparseIndex._version, sparseIndex.data_ptr(), str(device), capturing, fused._capture_epoch if capturing else 0)
+    hit = _pos_cache.get(id(sparseIndex))
+    if hit is None or hit[0] != key or hit[1]() is not sparseIndex:
+        table = (sparseIndex.to(device).unsqueeze(0) + _depths_tensor(tuple(range(_POS_DEPTHS)), device).unsqueeze(1)).to(torch.int32)
+        if len(_pos_cache) > 64:
+            _pos_cache.clear()
+        hit = _pos_cache[id(sparseIndex)] = (key, weakref.ref(sparseIndex), table)
+    return hit[2]
+
+
 def ctx_len_of(sparseIndex, device):
-    return (sparseIndex.to(device) + 1).to(torch.int32).contiguous()
+    return _position_table(sparseIndex, device)[1]
 
 
 def clearTree(root, clearAll=False, clearAttMask=False, clearSparseIndex=False):
@@ -250,7 +271,7 @@ def _attach_branch_gradients(generator, root, forwarded, device):
     sparseIndex = root.sparseIndex.to(device)
     all_ids = torch.stack([n.ids.detach() for n in forwarded], dim=1).reshape(B, N * K).to(device)
     depths = _depths_tensor(tuple(n.depth for n in forwarded), device)
-    pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
+    pos = _position_table(sparseIndex, device).index_select(0, depths).reshape(1, N * K).expand(B, -1)
     L = len(root.past)
     past = BranchPast(text=[root.past[l] for l in range(L)], ancestors=[[] for _ in range(L)],
                       ctx_len=ctx_len_of(sparseIndex, device), paths=paths, n_query_nodes=N)
@@ -373,7 +394,7 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
         paths = [[index[id(a)] for a in n.ancestors()] + [i] for i, n in enumerate(nodes)]
         all_ids = torch.stack([n.ids.detach() for n in nodes], dim=1).reshape(B, N * K).to(device)
         depths = _depths_tensor(tuple(n.depth for n in nodes), device)
-        pos = (sparseIndex.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, N * K).expand(B, -1).to(torch.int32)
+        pos = _position_table(sparseIndex, device).index_select(0, depths).reshape(1, N * K).expand(B, -1)
         tree_args = (K, N, paths, all_ids, pos, ctx_len_of(sparseIndex, device))
 
     def node_outputs(pred, inV, altV, kv, K, N):
