@@ -300,6 +300,12 @@ class _LMBase(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
+    def generate(self, input_ids, **kwargs):
+        """HF-style `model.generate(ids, max_new_tokens=..., do_sample=..., temperature=..., pad_token_id=...)` (what
+        Inference/GenerateTexts.py:19 calls): branchgan.generate.generate."""
+        from . import generate as _generate
+        return _generate.generate(self, input_ids, **kwargs)
+
     def supportsMergedTree(self, input_ids):
         """Can text and tree nodes go through ONE forward (BranchPast.merged_text)?  Only on the fused block path."""
         return getattr(self, "_fused_family", None) == "gpt2" and _fused_eligible(self, input_ids, None, None, False)

@@ -518,8 +518,25 @@ def g8_dataloader():
     print("wrote", path)
 
 
+def g9_text_metrics():
+    """Generated-text metrics: Training/Metrics/GeneratedTextsMetric.py on random id sequences."""
+    import json
+    from Training.Metrics import GeneratedTextsMetric as GT
+    rng = np.random.RandomState(9)
+    pairs = [(rng.randint(0, 40, 24).tolist(), rng.randint(0, 60, 16).tolist()) for _ in range(7)]
+    orig, gen = rng.rand(7).tolist(), (rng.rand(7) * 2).tolist()
+    out = dict(pairs=pairs, ttr=[list(map(float, GT.TTR(c, g))) for c, g in pairs], mean_ttr=list(map(float, GT.calculateTTR(pairs))),
+               original=orig, generated=gen, self_cce={k: float(v) for k, v in GT.selfCrossEntropy(orig, gen).items()})
+    path = os.path.join(OUT, "g9_text_metrics.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path)
+
+
 def main():
     torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
+    if sys.argv[1:] == ["g9"]:
+        return g9_text_metrics()
     if sys.argv[1:] == ["g8"]:
         return g8_dataloader()
     if sys.argv[1:] == ["g6"]:
@@ -529,6 +546,7 @@ def main():
     g6_schedules()
     g7_metrics()
     g8_dataloader()
+    g9_text_metrics()
     g1_attention()
     g2_sampling()
     g4_losses()
