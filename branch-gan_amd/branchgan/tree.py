@@ -43,7 +43,7 @@ class PredictionTreeNode:
         isRandomSamples = [False] * ids.shape[1] if isRandomSamples is None else isRandomSamples
         for i in range(ids.shape[1]):
             beam = i if self.parent is None else self.beam
-            self.children.append(PredictionTreeNode(ids[:, i], self, self.depth + 1, beam, probs[:, :, i], isRandomSamples[i],
+            self.children.append(PredictionTreeNode(ids[:, i], self, self.depth + 1, beam, None if probs is None else probs[:, :, i], isRandomSamples[i],
                                                     sparseIndex=self.sparseIndex, rootSeqSize=self.rootSeqSize,
                                                     logProbs=None if logProbs is None else logProbs[:, :, i]))
 
@@ -254,12 +254,28 @@ def _set_child_log_probs(node, lp):
         child.probs = child.logProbs.exp()
 
 
-def _attach_branch_gradients(generator, root, forwarded, device):
+_row_map_cache = {}
+
+
+def _node_rows(B, N, K, i, device):
+    """Rows of node i in the flattened (B * N * K, V) logits of a tree pass."""
+    key = (B, N, K, i, str(device))
+    if key not in _row_map_cache:
+        _row_map_cache[key] = (torch.arange(B, device=device).unsqueeze(1) * (N * K) + i * K + torch.arange(K, device=device).unsqueeze(0)).reshape(-1)
+    return _row_map_cache[key]
+
+
+def _attach_branch_gradients(generator, root, forwarded, device, pending=(), noise_fn=None):
     """Gives the children of every forwarded branch node autograd-connected log probs: one tree pass over all of them
-    (<= BG_MAX_SLOTS nodes), else node by node in depth order."""
+    (<= BG_MAX_SLOTS nodes), else node by node in depth order.  `pending`: (node, strategy, params, numAlterations) of the
+    deepest nodes, which have not been forwarded at all yet: they ride in the same pass and their children are sampled from
+    ITS logits - the same numbers a separate branch step over them would compute, one forward less per step."""
+    forwarded = list(forwarded) + [p[0] for p in pending]
+    n_done = len(forwarded) - len(pending)
     B, K = forwarded[0].ids.shape
     N = len(forwarded)
     if N > ops.MAX_SLOTS:
+        assert not pending
         for node in forwarded:
             ids = torch.stack([c.ids for c in node.children], dim=1)
             lp, past, _ = _branch_step(generator, node, device, None, ids.shape[1], None, None, None, ids=ids)
@@ -277,6 +293,12 @@ def _attach_branch_gradients(generator, root, forwarded, device):
                       ctx_len=ctx_len_of(sparseIndex, device), paths=paths, n_query_nodes=N)
     out = generator.forward({'input_ids': all_ids, 'position_ids': pos, 'textualPast': past, 'returnLmLogits': True,
                              'use_cache': False})
+    if pending:
+        logits2d = out.prediction.logits.detach().reshape(B * N * K, -1)
+        with torch.no_grad():
+            for i, (node, strat, params, numAlterations) in enumerate(pending, start=n_done):
+                ids = _sample_rows(logits2d, _node_rows(B, N, K, i, device), None, numAlterations, strat, params, B, K, noise_fn)
+                node.addGeneratorPredictionToNode(ids, None, None, None, getRandomNodesFromRule(strat, params, numAlterations))
     n_max = max(len(n.children) for n in forwarded)
     gather = torch.full((B, N, K, n_max), -1, dtype=torch.int64, device=device)
     for i, n in enumerate(forwarded):
@@ -337,8 +359,9 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
     # reference's per-node graph (MultiStepPrediction.py:296-327); dropout would draw different masks, so it keeps the old way.
     track = torch.is_grad_enabled() and logits.requires_grad
     deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules)
-    forwarded = []
-    for rule in sampleRules[1:]:
+    forwarded, pending = [], []
+    rules = sampleRules[1:]
+    for r_i, rule in enumerate(rules):
         for node in root.getLeaves(rule.continueFromRandom):
             if node.beam == 0 and rule.firstBeamSamplingStrategy is not None:
                 strat, params = rule.firstBeamSamplingStrategy, rule.firstBeamSamplingParams
@@ -347,14 +370,25 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
                 strat, params, numAlterations = rule.samplingStrategy, rule.samplingParams, rule.numAlterations
             params['includeFinalTimeStep'] = True
             params['blockSamplingOfLabels'] = False
+            if deferred and r_i == len(rules) - 1:
+                pending.append((node, strat, params, numAlterations))       # the deepest nodes: sampled from the gradient pass itself
+                continue
             with torch.no_grad() if deferred else contextlib.nullcontext():
                 lp, past, altIDs = _branch_step(generator, node, device, rule.samplingParams.get('dropoutRate', None),
                                                 numAlterations, strat, params, noise_fn)
             node.addGeneratorPredictionToNode(altIDs, past, None, lp.exp(), getRandomNodesFromRule(strat, params, numAlterations),
                                               logProbs=lp)
             forwarded.append(node)
-    if deferred and forwarded:
-        _attach_branch_gradients(generator, root, forwarded, device)
+    if pending and len(forwarded) + len(pending) > ops.MAX_SLOTS:          # too many nodes for one pass: a branch step each
+        for node, strat, params, numAlterations in pending:
+            with torch.no_grad():
+                lp, past, altIDs = _branch_step(generator, node, device, None, numAlterations, strat, params, noise_fn)
+            node.addGeneratorPredictionToNode(altIDs, past, None, lp.exp(), getRandomNodesFromRule(strat, params, numAlterations),
+                                              logProbs=lp)
+            forwarded.append(node)
+        pending = []
+    if deferred and (forwarded or pending):
+        _attach_branch_gradients(generator, root, forwarded, device, pending, noise_fn)
     if clearTreePast or clearFullTree:
         clearTree(root, clearFullTree)
     return root, firstOutput.prediction, firstOutput.classProbs, \
