@@ -25,7 +25,8 @@ def _sync_after_replay():
     env = os.environ.get("BRANCHGAN_GRAPH_SYNC")
     if env is not None:
         return env == "1"
-    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    from .training import REHEARSE_RCCL
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and (torch.distributed.get_world_size() > 1 or REHEARSE_RCCL)
 
 
 def _require_fused_path(model, example_ids):

@@ -46,13 +46,19 @@ def worker_batch_size(batchSize, worldSize, rank):
     return batchSize // worldSize + (1 if rank < batchSize % worldSize else 0)
 
 
+# BRANCHGAN_REHEARSE_RCCL=1: run the multi-rank code path (process group, bucketed all-reduce on the side stream, the graph
+# schedule's host syncs and deferred discriminator step) with ONE rank - the only way to put RCCL itself under the graph replay
+# schedule on a one-GPU box.
+REHEARSE_RCCL = os.environ.get("BRANCHGAN_REHEARSE_RCCL") == "1"
+
+
 def init_data_parallel(backend=None):
     """Reads the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), one process per GPU.
     backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or REHEARSE_RCCL) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "12345")
         # BRANCHGAN_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU (RCCL refuses that)
@@ -104,7 +110,7 @@ class GradArena:
         if self.arena is None:
             self._build()
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 and not (REHEARSE_RCCL and dist.is_initialized()):
             return
         per = max(1, self.bucket_bytes // 4)
         buckets = [self.arena[i:i + per] for i in range(0, self.arena.numel(), per)]

@@ -62,6 +62,27 @@ __device__ __forceinline__ void row_foreach(const float* x, int64_t V, F f) {
   }
 }
 
+// The same walk with every lane of the wave calling f together (valid = false outside the row): for bodies that use
+// wave-wide operations (ballots) or wave-uniform state.
+template <typename F>
+__device__ __forceinline__ void row_foreach_converged(const float* x, int64_t V, F f) {
+  const int mis = (int)((((uintptr_t)x) & 15) / sizeof(float));
+  for (int64_t cb = -mis; cb < V; cb += RS_THREADS * 4) {
+    const int64_t i0 = cb + (int64_t)threadIdx.x * 4;
+    float v[4];
+    if (i0 >= 0 && i0 + 4 <= V) {
+      const f32x4 raw = *(const f32x4*)(x + i0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? x[i0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f(v[j], i0 + j >= 0 && i0 + j < V);
+  }
+}
+
 // fixed-order block reductions: lanes by xor-shuffle, then the 8 wave results in wave order; result in every thread
 template <typename T, typename Op>
 __device__ __forceinline__ T block_reduce(T v, T* scratch, Op op) {
@@ -103,6 +124,74 @@ __device__ __forceinline__ void find_rank(const uint32_t* hist, uint32_t r, uint
 #pragma unroll
   for (int j = PER - 1; j >= 0; --j) {
     if (above < r && r <= above + h[j]) { out[0] = (uint32_t)(t * PER + j); out[1] = above; }
+    above += h[j];
+  }
+  __syncthreads();
+}
+
+// Bitonic sort (descending) of 2048 keys held four per thread, element index e = 4 t + r: partners four or more apart sit in
+// another lane (strides 4 .. 128: a wave shuffle) or another wave (strides 256 .. 1024: through `xch`, 2048 words of LDS,
+// two barriers); strides 1 and 2 stay in the thread's own registers.  6 of the 66 stages touch LDS.
+__device__ __forceinline__ void sort2048_desc(uint32_t (&k)[4], uint32_t* xch) {
+  const uint32_t t = threadIdx.x;
+#pragma unroll
+  for (uint32_t size = 2; size <= 2048; size <<= 1) {
+#pragma unroll
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      uint32_t other[4];
+      if (stride >= 256) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[4 * t + r] = k[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) other[r] = xch[4 * (t ^ (stride >> 2)) + r];
+      } else if (stride >= 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) other[r] = (uint32_t)__shfl_xor((int)k[r], (int)(stride >> 2));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) other[r] = k[r ^ (int)stride];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t e = 4 * t + r;
+        const bool take_max = ((e & stride) == 0) == ((e & size) == 0);
+        const uint32_t hi = k[r] > other[r] ? k[r] : other[r], lo = k[r] > other[r] ? other[r] : k[r];
+        k[r] = take_max ? hi : lo;
+      }
+    }
+  }
+}
+
+// find_rank for several ranks of ONE histogram: one scan, every thread tests all ranks against its bins.
+template <int PER>
+__device__ __forceinline__ void find_ranks(const uint32_t* hist, const uint32_t (&r)[BG_MAX_RANKS], int nr, uint32_t* wave_tot, uint32_t* out) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t h[PER], tot = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { h[j] = hist[t * PER + j]; tot += h[j]; }
+  uint32_t inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < RS_WAVES; ++w) {
+    if (w < wave) before += wave_tot[w];
+    total += wave_tot[w];
+  }
+  uint32_t above = total - (before + inc);
+#pragma unroll
+  for (int j = PER - 1; j >= 0; --j) {
+#pragma unroll
+    for (int i = 0; i < BG_MAX_RANKS; ++i)
+      if (i < nr && above < r[i] && r[i] <= above + h[j]) { out[2 * i] = (uint32_t)(t * PER + j); out[2 * i + 1] = above; }
     above += h[j];
   }
   __syncthreads();
@@ -168,12 +257,8 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   __syncthreads();
   uint32_t want[BG_MAX_RANKS], prefix[BG_MAX_RANKS], above[BG_MAX_RANKS];      // uniform across the block
 #pragma unroll
-  for (int i = 0; i < BG_MAX_RANKS; ++i) {
-    if (i < nr) {
-      want[i] = (uint32_t)(a.ranks[i] < V ? a.ranks[i] : V);
-      find_rank<RS_BINS / RS_THREADS>(hist, want[i], wave_tot, sel + 2 * i);
-    }
-  }
+  for (int i = 0; i < BG_MAX_RANKS; ++i) want[i] = i < nr ? (uint32_t)(a.ranks[i] < V ? a.ranks[i] : V) : 0u;
+  find_ranks<RS_BINS / RS_THREADS>(hist, want, nr, wave_tot, sel);
 #pragma unroll
   for (int i = 0; i < BG_MAX_RANKS; ++i) {
     if (i < nr) { prefix[i] = sel[2 * i]; above[i] = sel[2 * i + 1]; }
@@ -182,8 +267,7 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
 
   // ---- fast path: everything a rank can need lies in the buckets at and above the lowest selected one.  When those hold at
   // most RS_CAND keys (for next-token distributions: the requested ranks plus a few hundred), ONE more pass over the row
-  // compacts them into LDS, a bitonic sort orders them, and each top mass is a prefix sum of the sorted keys - in the sorted
-  // order, so the result does not depend on the order the compaction's atomics happened to run in.
+  // compacts them into LDS, a bitonic sort orders them, and each top mass is a prefix sum of the sorted keys.
   uint32_t b_min = prefix[0], n_cand = 0;
 #pragma unroll
   for (int i = 0; i < BG_MAX_RANKS; ++i) {
@@ -195,49 +279,103 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   }
   __syncthreads();                                      // hist[] was read above and is overwritten below
   if (n_cand <= RS_CAND) {
-    uint32_t* cand = lds;                               // [0, n_pad) keys; the counter lives behind the scratch words
-    uint32_t* counter = scratch + 40;
-    uint32_t n_pad = 64;
-    while (n_pad < n_cand) n_pad <<= 1;
-    for (uint32_t i = t; i < n_pad; i += RS_THREADS) cand[i] = 0u;                // key 0 sorts below every real value
-    if (t == 0) *counter = 0u;
-    __syncthreads();
-    const int lane = t & 63;
-    row_foreach(x, V, [&](float v, int64_t) {
+    // Compaction without atomics: wave w appends to its own region [w * RS_CAND / 8, ...) at a wave-uniform count kept in a
+    // register (ballot + popcount), then the eight regions are packed into one run.  A wave that meets more than its region
+    // holds sends the row down the general path.
+    constexpr uint32_t REGION = RS_CAND / RS_WAVES;
+    const int lane = t & 63, wave = t >> 6;
+    uint32_t* region = lds + wave * REGION;
+    uint32_t wcount = 0;
+    row_foreach_converged(x, V, [&](float v, bool valid) {
       const uint32_t k = order_key(v);
-      const bool take = (k >> 21) >= b_min;
-      const uint64_t m = __ballot(take);                // one counter update per wave instruction, not one per element
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (take) cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
-      }
+      const bool take = valid && (k >> 21) >= b_min;
+      const uint64_t m = __ballot(take);
+      const uint32_t at = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (take && at < REGION) region[at] = k;
+      wcount += (uint32_t)__popcll(m);
     });
+    if (lane == 0) wave_tot[wave] = wcount;
     __syncthreads();
-    for (uint32_t size = 2; size <= n_pad; size <<= 1) {                           // bitonic sort, descending
-      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-        for (uint32_t i = t; i < (n_pad >> 1); i += RS_THREADS) {
-          const uint32_t lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
-          const uint32_t p = cand[lo], q = cand[hi];
-          const bool desc = (lo & size) == 0;
-          if (desc ? p < q : p > q) { cand[lo] = q; cand[hi] = p; }
-        }
-        __syncthreads();
-      }
-    }
-    const uint32_t per = (n_pad + RS_THREADS - 1) / RS_THREADS;                    // thread t sums cand[t * per, (t + 1) * per)
+    uint32_t start = 0, worst = 0;
 #pragma unroll
-    for (int i = 0; i < BG_MAX_RANKS; ++i) {
-      if (i < nr) {
-        float s = 0.f;
-        for (uint32_t j = t * per; j < (t + 1) * per && j < want[i]; ++j) s += key_value(cand[j]);
-        s = block_reduce(s, (float*)scratch, [](float p, float q) { return p + q; });
-        if (t == 0) a.top_mass[row * nr + i] = s;
-      }
+    for (int w = 0; w < RS_WAVES; ++w) {
+      if (w < wave) start += wave_tot[w];
+      worst = wave_tot[w] > worst ? wave_tot[w] : worst;
     }
-    return;
+    if (worst <= REGION) {
+      uint32_t* cand = lds + RS_CAND;                     // [0, n_pad) keys, packed behind the regions
+      uint32_t n_pad = 64;
+      while (n_pad < n_cand) n_pad <<= 1;
+      for (uint32_t i = t; i < n_pad; i += RS_THREADS) cand[i] = 0u;                // key 0 sorts below every real value
+      __syncthreads();
+      for (uint32_t j = (uint32_t)lane; j < wcount; j += 64) cand[start + j] = region[j];
+      __syncthreads();
+      if (n_pad <= 2048) {                                // the usual case: sort in registers, four keys per thread
+        uint32_t k4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) k4[r] = 4 * (uint32_t)t + r < n_pad ? cand[4 * t + r] : 0u;
+        sort2048_desc(k4, lds);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cand[4 * t + r] = k4[r];
+        n_pad = 2048;
+        __syncthreads();
+      } else {
+        // Bitonic sort, descending, in LDS.  Every wave owns a contiguous n_pad / 8 keys: the stages whose partners lie inside one such
+        // chunk (all of them up to that size, and the tail of every later size) run without a workgroup barrier - LDS operations
+        // of one wave execute in order - which leaves 21 barriers for 8192 keys instead of 91.
+        {
+          volatile uint32_t* vc = cand;
+          const uint32_t chunk = n_pad / RS_WAVES, wbase = (uint32_t)(t >> 6) * chunk;
+          auto exchange = [&](uint32_t lo, uint32_t hi, uint32_t size) {
+            const uint32_t p = vc[lo], q = vc[hi];
+            const bool desc = (lo & size) == 0;
+            if (desc ? p < q : p > q) { vc[lo] = q; vc[hi] = p; }
+          };
+          for (uint32_t size = 2; size <= n_pad; size <<= 1) {
+            uint32_t stride = size >> 1;
+            for (; 2 * stride > chunk; stride >>= 1) {                                   // partners in different chunks
+              for (uint32_t i = t; i < (n_pad >> 1); i += RS_THREADS) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                exchange(lo, lo + stride, size);
+              }
+              __syncthreads();
+            }
+            for (; stride > 0; stride >>= 1) {                                           // inside the wave's own chunk
+              for (uint32_t pi = (uint32_t)lane; pi < (chunk >> 1); pi += 64) {
+                const uint32_t lo = wbase + 2 * pi - (pi & (stride - 1));
+                exchange(lo, lo + stride, size);
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+            if (2 * size > chunk) __syncthreads();                                       // the next size reaches across chunks
+          }
+          __syncthreads();
+        }
+      }
+      // top masses: thread t sums cand[t * per, (t + 1) * per) below each rank, lanes by shuffle, waves in order
+      const uint32_t per = (n_pad + RS_THREADS - 1) / RS_THREADS;
+      float* part = (float*)lds;                                                        // [wave][rank]; the regions are free again
+  #pragma unroll
+      for (int i = 0; i < BG_MAX_RANKS; ++i) {
+        if (i < nr) {
+          float sm = 0.f;
+          for (uint32_t j = t * per; j < (t + 1) * per && j < want[i]; ++j) sm += key_value(cand[j]);
+  #pragma unroll
+          for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+          if (lane == 0) part[(t >> 6) * BG_MAX_RANKS + i] = sm;
+        }
+      }
+      __syncthreads();
+      if (t < nr) {
+        float sm = part[t];
+  #pragma unroll
+        for (int w = 1; w < RS_WAVES; ++w) sm += part[w * BG_MAX_RANKS + t];
+        a.top_mass[row * nr + t] = sm;
+      }
+      return;
+    }
+    __syncthreads();                                    // a region overflowed: the general path reuses the histogram words
   }
 
   // ---- general path (flat rows: more than RS_CAND keys share the selected buckets): two more radix levels over the row ----------

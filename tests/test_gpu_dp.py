@@ -92,3 +92,21 @@ def test_two_ranks_on_one_gpu():
     for k, v in ref.items():
         moved = max(moved, float((v - init[k]).abs().max()))
     assert moved > 1e-3          # the steps did train something
+
+
+def test_rccl_one_rank_rehearsal_of_the_multi_rank_schedule():
+    """BRANCHGAN_REHEARSE_RCCL=1: process group on the nccl (= RCCL) backend, bucketed all-reduces on the side stream, host
+    syncs after graph replays and the deferred discriminator step - with the ONE rank a one-GPU box allows.  Guards against
+    the RCCL-side hang a 2-rank gloo rehearsal cannot show; the bench line must come out with finite losses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BRANCHGAN_REHEARSE_RCCL="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert all(abs(v) < 1e4 for v in line["config"]["final_losses"].values())

@@ -28,7 +28,7 @@ def _reference(x, labels, ranks, eps):
 
 
 @pytest.mark.parametrize("rows,V", [(7, 97), (5, 1031), (3, 50257), (4, 50304), (2, 4096)])
-@pytest.mark.parametrize("kind", ["softmax", "ties", "signed"])
+@pytest.mark.parametrize("kind", ["softmax", "ties", "flat", "signed"])
 def test_rank_stats_matches_sort(rows, V, kind):
     from branchgan import ops
     g = torch.Generator().manual_seed(rows * 131 + V)
@@ -36,6 +36,8 @@ def test_rank_stats_matches_sort(rows, V, kind):
         x = torch.softmax(3 * torch.randn(rows, V, generator=g), -1)
     elif kind == "ties":                                   # 16 distinct values: every threshold sits inside a run of equal values
         x = torch.randint(0, 16, (rows, V), generator=g).float() / 64
+    elif kind == "flat":                                   # two values: at V = 50k far more candidates than LDS holds (general path)
+        x = (1 + torch.randint(0, 2, (rows, V), generator=g).float()) / 64
     else:                                                  # negative values, zeros of both signs, an infinity
         x = torch.randn(rows, V, generator=g)
         x[:, ::7] = 0.0
@@ -58,7 +60,7 @@ def test_rank_stats_matches_sort(rows, V, kind):
         assert torch.equal(torch.isfinite(got["top_mass"]), finite)
         torch.testing.assert_close(got["top_mass"][finite].double(), want["top_mass"][finite], rtol=1e-5, atol=1e-3)
     else:
-        torch.testing.assert_close(got["top_mass"].double(), want["top_mass"], rtol=0, atol=2e-6 * (64 if kind == "ties" else 1) * max(1, V // 4096))
+        torch.testing.assert_close(got["top_mass"].double(), want["top_mass"], rtol=0, atol=2e-6 * (64 if kind in ("ties", "flat") else 1) * max(1, V // 4096))
         torch.testing.assert_close(got["entropy"].double(), want["entropy"], rtol=1e-5, atol=1e-5)
 
 
