@@ -180,20 +180,26 @@ class _DeferredReductions:
     def __init__(self, device):
         self.device = device
         self.chunks, self.cur, self.off = [], 0, 0
-        self.pending, self.streams, self.armed = [], set(), False
+        self.pending, self.streams, self.armed, self.task = [], set(), False, -1
 
     def begin(self):
-        """Called by a producer about to defer.  False: not inside a backward pass (no engine callback possible), reduce now."""
-        if self.armed:
+        """Called by a producer about to defer.  False: not inside a backward pass (no engine callback possible), reduce now.
+        The callback is queued once per backward pass (autograd graph task).  Reductions still pending from ANOTHER pass - a
+        reentrant backward inside this one, or a pass that raised before its callback ran - are reduced first: none is ever
+        lost, and their workspace is free again."""
+        task = torch._C._current_graph_task_id()
+        if task < 0:
+            return False
+        if self.armed and self.task == task:
             return True
-        self.pending.clear()            # leftovers of a backward pass that raised before its callback ran
-        self.streams.clear()
-        self.cur = self.off = 0
+        if self.pending:
+            self.flush()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
         except RuntimeError:
+            self.armed = False
             return False
-        self.armed = True
+        self.armed, self.task = True, task
         return True
 
     def alloc(self, nbytes):

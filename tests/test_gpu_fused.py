@@ -329,9 +329,14 @@ def test_deferred_reductions_match_immediate_ones(monkeypatch):
     for dtype in (None, torch.bfloat16):
         now = run(False, dtype)
         d = fused._deferred_for(ids.device)
-        d.pending.append((0, None, 1, 1, 1))     # what a backward pass that raised would leave: must be dropped, not reduced
+        # what a backward pass that raised before its callback ran leaves behind: a pending reduction, armed for a dead task.
+        # The next pass must reduce it (exactly once) before it reuses the workspace, and then run normally.
+        left_part, left_out = torch.ones(3, 5, device="cuda"), torch.zeros(5, device="cuda")
+        d.pending.append((left_part.data_ptr(), left_out, 3, 5, 5))
+        d.armed, d.task = True, -5
         later = run(True, dtype)
         assert not d.pending and not d.armed
+        assert torch.equal(left_out, torch.full((5,), 3.0, device="cuda"))
         for a, b in zip(now, later):
             assert set(a) == set(b)
             for n in a:
