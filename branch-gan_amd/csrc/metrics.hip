@@ -44,20 +44,33 @@ __device__ __forceinline__ float key_value(uint32_t k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// f(value, index) over the row: aligned 16-byte loads, scalar head / tail (V and the row stride need not be multiples of 4)
+// f(value, index) over the row: aligned 16-byte loads, scalar head / tail (V and the row stride need not be multiples of 4).
+// Four vectors per thread are requested before the first is used: at two workgroups per CU a single 16-byte load per thread
+// in flight covers a quarter of the bytes HBM latency needs outstanding.
 template <typename F>
 __device__ __forceinline__ void row_foreach(const float* x, int64_t V, F f) {
+  constexpr int UN = 4;
   const int mis = (int)((((uintptr_t)x) & 15) / sizeof(float));
-  for (int64_t cb = -mis; cb < V; cb += RS_THREADS * 4) {
-    const int64_t i0 = cb + (int64_t)threadIdx.x * 4;
-    if (i0 >= 0 && i0 + 4 <= V) {
-      const f32x4 raw = *(const f32x4*)(x + i0);
+  for (int64_t cb = -mis; cb < V; cb += (int64_t)UN * RS_THREADS * 4) {
+    f32x4 raw[UN];
+    bool whole[UN];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f(raw[j], i0 + j);
-    } else {
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i0 = cb + ((int64_t)u * RS_THREADS + threadIdx.x) * 4;
+      whole[u] = i0 >= 0 && i0 + 4 <= V;
+      if (whole[u]) raw[u] = *(const f32x4*)(x + i0);
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (i0 + j >= 0 && i0 + j < V) f(x[i0 + j], i0 + j);
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i0 = cb + ((int64_t)u * RS_THREADS + threadIdx.x) * 4;
+      if (whole[u]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f(raw[u][j], i0 + j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (i0 + j >= 0 && i0 + j < V) f(x[i0 + j], i0 + j);
+      }
     }
   }
 }
@@ -66,20 +79,28 @@ __device__ __forceinline__ void row_foreach(const float* x, int64_t V, F f) {
 // wave-wide operations (ballots) or wave-uniform state.
 template <typename F>
 __device__ __forceinline__ void row_foreach_converged(const float* x, int64_t V, F f) {
+  constexpr int UN = 4;
   const int mis = (int)((((uintptr_t)x) & 15) / sizeof(float));
-  for (int64_t cb = -mis; cb < V; cb += RS_THREADS * 4) {
-    const int64_t i0 = cb + (int64_t)threadIdx.x * 4;
-    float v[4];
-    if (i0 >= 0 && i0 + 4 <= V) {
-      const f32x4 raw = *(const f32x4*)(x + i0);
+  for (int64_t cb = -mis; cb < V; cb += (int64_t)UN * RS_THREADS * 4) {
+    float v[UN][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = raw[j];
-    } else {
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i0 = cb + ((int64_t)u * RS_THREADS + threadIdx.x) * 4;
+      if (i0 >= 0 && i0 + 4 <= V) {
+        const f32x4 raw = *(const f32x4*)(x + i0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? x[i0 + j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[u][j] = raw[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[u][j] = (i0 + j >= 0 && i0 + j < V) ? x[i0 + j] : 0.f;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f(v[j], i0 + j >= 0 && i0 + j < V);
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i0 = cb + ((int64_t)u * RS_THREADS + threadIdx.x) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f(v[u][j], i0 + j >= 0 && i0 + j < V);
+    }
   }
 }
 
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
     const uint32_t k = order_key(v);
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
-    ent += v * logf(v + eps);
+    ent += v * __logf(v + eps);            // v_log_f32: 1 ulp, far inside the metric's tolerance
     n_gt += k > kl;
     n_eq_before += (k == kl) & (j < label);
     if (nr > 0) atomicAdd(&my_hist[k >> 21], 1u);
