@@ -10,7 +10,7 @@
 // an MSD radix select on the order-preserving integer image of the floats (11 + 11 + 10 bits): a 2048-bin histogram that
 // tells which buckets hold the requested ranks.  Pass 2 (row now in L2 / MALL) compacts the keys of those buckets and
 // everything above them into LDS - for next-token distributions little more than the largest requested rank - where they are
-// sorted and prefix-summed.  Rows too flat for that (more than 8192 keys in the selected buckets) take two more radix levels
+// sorted and prefix-summed.  Rows too flat for that (more than 4096 keys in the selected buckets) take two more radix levels
 // and a summing pass over the row instead.  Histogram counters are LDS atomics on integers (exact, order-free); every
 // floating-point sum runs in a fixed order, so results are bit-reproducible.  HBM-bound: algorithmic bytes = one read of the row.
 #include "common.h"
@@ -20,7 +20,9 @@ namespace bg {
 constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_BINS = 2048;      // 11-bit digits (the last level uses 1024 of them)
-constexpr int RS_CAND = 8192;      // keys the fast path sorts in LDS
+constexpr int RS_CAND = 4096;      // keys the fast path sorts in LDS
+constexpr int RS_GROUP = 4;        // ranks the general path refines per sweep (LDS: RS_GROUP histograms of 2048 bins = 32 KB,
+                                   // four workgroups per CU)
 
 struct RankStatsArgs {
   const float* x;
@@ -219,10 +221,10 @@ __device__ __forceinline__ void find_ranks(const uint32_t* hist, const uint32_t 
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a) {
-  // [0, 16384): histograms (level 1: 8 lane-interleaved copies of 2048 bins; levels 2, 3: one histogram per rank)
-  __shared__ uint32_t lds[BG_MAX_RANKS * RS_BINS + 64];
+  // [0, 8192): histograms (level 1: 4 lane-interleaved copies of 2048 bins; levels 2, 3: one histogram per rank of a group)
+  __shared__ uint32_t lds[RS_GROUP * RS_BINS + 64];
   uint32_t* hist = lds;
-  uint32_t* scratch = lds + BG_MAX_RANKS * RS_BINS;     // 8 words of reduction scratch, 8 of wave totals, 2 per rank of results
+  uint32_t* scratch = lds + RS_GROUP * RS_BINS;     // 8 words of reduction scratch, 8 of wave totals, 2 per rank of results
   uint32_t* wave_tot = scratch + 8;
   uint32_t* sel = scratch + 16;                         // sel[2 i] = bin, sel[2 i + 1] = count above, for rank i
 
@@ -236,13 +238,13 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   const uint32_t kl = order_key(xl);
   const int nr = a.n_ranks;
 
-  for (int i = t; i < 8 * RS_BINS; i += RS_THREADS) hist[i] = 0;
+  for (int i = t; i < 4 * RS_BINS; i += RS_THREADS) hist[i] = 0;
   __syncthreads();
 
   // ---- pass 1 ---------------------------------------------------------------------------------------------------------
   float mn = INFINITY, mx = -INFINITY, ent = 0.f;
   uint32_t n_gt = 0, n_eq_before = 0;
-  uint32_t* my_hist = hist + (t & 7) * RS_BINS;      // probabilities crowd into a few exponent bins: spread the same-address atomics
+  uint32_t* my_hist = hist + (t & 3) * RS_BINS;      // probabilities crowd into a few exponent bins: spread the same-address atomics
   const float eps = a.eps;
   row_foreach(x, V, [&](float v, int64_t j) {
     const uint32_t k = order_key(v);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
   for (int i = t; i < RS_BINS; i += RS_THREADS) {
     uint32_t c = hist[i];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) c += hist[k * RS_BINS + i];
+    for (int k = 1; k < 4; ++k) c += hist[k * RS_BINS + i];
     hist[i] = c;
   }
   __syncthreads();
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
       } else {
         // Bitonic sort, descending, in LDS.  Every wave owns a contiguous n_pad / 8 keys: the stages whose partners lie inside one such
         // chunk (all of them up to that size, and the tail of every later size) run without a workgroup barrier - LDS operations
-        // of one wave execute in order - which leaves 21 barriers for 8192 keys instead of 91.
+        // of one wave execute in order - which leaves 15 barriers for 4096 keys instead of 78.
         {
           volatile uint32_t* vc = cand;
           const uint32_t chunk = n_pad / RS_WAVES, wbase = (uint32_t)(t >> 6) * chunk;
@@ -399,45 +401,51 @@ __global__ __launch_bounds__(RS_THREADS) void rank_stats_kernel(RankStatsArgs a)
     __syncthreads();                                    // a region overflowed: the general path reuses the histogram words
   }
 
-  // ---- general path (flat rows: more than RS_CAND keys share the selected buckets): two more radix levels over the row ----------
-  // level 2: the next 11 bits among the elements whose top 11 bits equal the rank's bucket
-  for (int i = t; i < nr * RS_BINS; i += RS_THREADS) hist[i] = 0;
-  __syncthreads();
-  row_foreach(x, V, [&](float v, int64_t) {
-    const uint32_t k = order_key(v);
+  // ---- general path (flat rows: more than RS_CAND keys share the selected buckets): two more radix levels and a summing pass
+  // over the row, RS_GROUP ranks at a time
 #pragma unroll
-    for (int i = 0; i < BG_MAX_RANKS; ++i)
-      if (i < nr && (k >> 21) == prefix[i]) atomicAdd(&hist[i * RS_BINS + ((k >> 10) & 0x7FFu)], 1u);
-  });
-  __syncthreads();
+  for (int g0 = 0; g0 < BG_MAX_RANKS; g0 += RS_GROUP) {
+    if (g0 >= nr) break;
+    // level 2: the next 11 bits among the elements whose top 11 bits equal the rank's bucket
+    __syncthreads();
+    for (int i = t; i < RS_GROUP * RS_BINS; i += RS_THREADS) hist[i] = 0;
+    __syncthreads();
+    row_foreach(x, V, [&](float v, int64_t) {
+      const uint32_t k = order_key(v);
 #pragma unroll
-  for (int i = 0; i < BG_MAX_RANKS; ++i)
-    if (i < nr) find_rank<RS_BINS / RS_THREADS>(hist + i * RS_BINS, want[i] - above[i], wave_tot, sel + 2 * i);
+      for (int ii = 0; ii < RS_GROUP; ++ii)
+        if (g0 + ii < nr && (k >> 21) == prefix[g0 + ii]) atomicAdd(&hist[ii * RS_BINS + ((k >> 10) & 0x7FFu)], 1u);
+    });
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < BG_MAX_RANKS; ++i) {
-    if (i < nr) { prefix[i] = (prefix[i] << 11) | sel[2 * i]; above[i] += sel[2 * i + 1]; }
-  }
-  __syncthreads();
+    for (int ii = 0; ii < RS_GROUP; ++ii)
+      if (g0 + ii < nr) find_rank<RS_BINS / RS_THREADS>(hist + ii * RS_BINS, want[g0 + ii] - above[g0 + ii], wave_tot, sel + 2 * ii);
+#pragma unroll
+    for (int ii = 0; ii < RS_GROUP; ++ii) {
+      if (g0 + ii < nr) { prefix[g0 + ii] = (prefix[g0 + ii] << 11) | sel[2 * ii]; above[g0 + ii] += sel[2 * ii + 1]; }
+    }
+    __syncthreads();
 
-  // level 3: the last 10 bits
-  for (int i = t; i < nr * RS_BINS; i += RS_THREADS) hist[i] = 0;
-  __syncthreads();
-  row_foreach(x, V, [&](float v, int64_t) {
-    const uint32_t k = order_key(v);
+    // level 3: the last 10 bits
+    for (int i = t; i < RS_GROUP * RS_BINS; i += RS_THREADS) hist[i] = 0;
+    __syncthreads();
+    row_foreach(x, V, [&](float v, int64_t) {
+      const uint32_t k = order_key(v);
 #pragma unroll
-    for (int i = 0; i < BG_MAX_RANKS; ++i)
-      if (i < nr && (k >> 10) == prefix[i]) atomicAdd(&hist[i * RS_BINS + (k & 0x3FFu)], 1u);
-  });
-  __syncthreads();
+      for (int ii = 0; ii < RS_GROUP; ++ii)
+        if (g0 + ii < nr && (k >> 10) == prefix[g0 + ii]) atomicAdd(&hist[ii * RS_BINS + (k & 0x3FFu)], 1u);
+    });
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < BG_MAX_RANKS; ++i)
-    if (i < nr) find_rank<1024 / RS_THREADS>(hist + i * RS_BINS, want[i] - above[i], wave_tot, sel + 2 * i);
+    for (int ii = 0; ii < RS_GROUP; ++ii)
+      if (g0 + ii < nr) find_rank<1024 / RS_THREADS>(hist + ii * RS_BINS, want[g0 + ii] - above[g0 + ii], wave_tot, sel + 2 * ii);
 #pragma unroll
-  for (int i = 0; i < BG_MAX_RANKS; ++i) {
-    if (i < nr) { prefix[i] = (prefix[i] << 10) | sel[2 * i]; above[i] += sel[2 * i + 1]; }      // prefix = key of the r-th largest
+    for (int ii = 0; ii < RS_GROUP; ++ii) {                       // prefix = key of the r-th largest
+      if (g0 + ii < nr) { prefix[g0 + ii] = (prefix[g0 + ii] << 10) | sel[2 * ii]; above[g0 + ii] += sel[2 * ii + 1]; }
+    }
   }
 
-  // ---- pass 4: the mass above each threshold; the threshold value itself fills the remaining (r - above) places -------------
+  // ---- last pass: the mass above each threshold; the threshold value itself fills the remaining (r - above) places ----------
   float acc[BG_MAX_RANKS];
 #pragma unroll
   for (int i = 0; i < BG_MAX_RANKS; ++i) acc[i] = 0.f;
