@@ -22,8 +22,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* k_row = (T*)smem;
   T* v_row = k_row + L::ROW_ELEMS;
-  T* k_col = v_row + L::ROW_ELEMS;  // bf16 only
-  int* red = (int*)(k_col + (sizeof(T) == 4 ? 0 : L::COL_ELEMS));
+  int* red = (int*)(v_row + L::ROW_ELEMS);
 
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -73,8 +72,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
   }
   for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
     __syncthreads();  // previous tile fully consumed
-    if constexpr (sizeof(T) == 4) kreg.template store<true, false>(k_row, nullptr, tid);
-    else kreg.template store<true, true>(k_row, k_col, tid);
+    kreg.template store<true, false>(k_row, nullptr, tid);
     vreg.template store<true, false>(v_row, nullptr, tid);
     __syncthreads();
     if (kb + ATT_TILE < block_ctx) {
@@ -94,7 +92,8 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
       const float p = (key < ctx) ? __expf(s[r] * sh.scale - lse) : 0.f;
       s[r] = p * (dp[r] - delta) * sh.scale;  // dS^T
     }
-    mma_reduce_rows<T, DH, 0, NDT>(dq, s, sizeof(T) == 4 ? k_row : k_col, lane);
+    if constexpr (sizeof(T) == 4) mma_reduce_rows<T, DH, 0, NDT>(dq, s, k_row, lane);
+    else mma_reduce_rows_tr<DH, 0, NDT>(dq, s, k_row, lane);
   }
 
   const int plen = valid ? a.path_len[n] : 0;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
 
 static size_t attn_dq_lds_bytes(int dtype, int Dh) {
   if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
-  return (size_t)(2 * ATT_TILE * (Dh + 8) + Dh * (ATT_TILE + 4)) * 2 + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 64;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -131,9 +130,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* q_row_l = (T*)smem;
   T* do_row_l = q_row_l + L::ROW_ELEMS;
-  T* q_col_l = do_row_l + L::ROW_ELEMS;                                   // bf16 only
-  T* do_col_l = q_col_l + (sizeof(T) == 4 ? 0 : L::COL_ELEMS);            // bf16 only
-  float* lse_s = (float*)(do_col_l + (sizeof(T) == 4 ? 0 : L::COL_ELEMS));
+  float* lse_s = (float*)(do_row_l + L::ROW_ELEMS);
   float* delta_s = lse_s + ATT_TILE;
   int* ctx_s = (int*)(delta_s + ATT_TILE);
 
@@ -230,13 +227,8 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
           do_row_l[r * L::RSTRIDE + d0 + j] = do_reg[i][j];
         }
       } else {
-        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = q_reg[i];
-        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = do_reg[i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          q_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = q_reg[i][j];
-          do_col_l[(d0 + j) * Lds<bf16_t, DH>::CSTRIDE + r] = do_reg[i][j];
-        }
+        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = q_reg[i];      // one image: read by rows for S / dP, by columns
+        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = do_reg[i];    // (transposed LDS reads) for dV / dK
       }
     }
     if (tid < ATT_TILE) {
@@ -265,8 +257,13 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
       dp[r] = p * (dp[r] - delta_s[row]) * sh.scale;  // dS
       s[r] = p;                                       // P
     }
-    mma_reduce_rows<T, DH, DT0, DT1>(dv, s, sizeof(T) == 4 ? do_row_l : do_col_l, lane);   // dV^T += dO^T·P
-    mma_reduce_rows<T, DH, DT0, DT1>(dk, dp, sizeof(T) == 4 ? q_row_l : q_col_l, lane);    // dK^T += Q^T·dS
+    if constexpr (sizeof(T) == 4) {
+      mma_reduce_rows<T, DH, DT0, DT1>(dv, s, do_row_l, lane);     // dV^T += dO^T·P
+      mma_reduce_rows<T, DH, DT0, DT1>(dk, dp, q_row_l, lane);     // dK^T += Q^T·dS
+    } else {
+      mma_reduce_rows_tr<DH, DT0, DT1>(dv, s, do_row_l, lane);
+      mma_reduce_rows_tr<DH, DT0, DT1>(dk, dp, q_row_l, lane);
+    }
   }
 
   if (kvalid) {
@@ -307,7 +304,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
 
 static size_t attn_dkv_lds_bytes(int dtype, int Dh) {
   if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 3 * ATT_TILE * 4 + 64;
-  return (size_t)(2 * ATT_TILE * (Dh + 8) + 2 * Dh * (ATT_TILE + 4)) * 2 + 3 * ATT_TILE * 4 + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 3 * ATT_TILE * 4 + 64;
 }
 
 // ---------------------------------------------------------------------------------------------------

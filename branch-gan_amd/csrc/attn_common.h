@@ -220,6 +220,33 @@ __device__ __forceinline__ void mma_reduce_rows(f32x16 (&out)[DH / 32], const f3
   }
 }
 
+// The same product with Z read from its ROW image (bf16, [tile row][RSTRIDE]) by gfx950's transposed LDS read: per 16-lane group
+// `ds_read_b64_tr_b16` takes a block of 4 rows x 16 columns and hands lane i column i of the four rows - exactly the A
+// operand above (d = dt * 32 + r on the lane, tile rows 16 s + 4 h + {0..3} and + 8) without a second, column-major copy of the
+// tile and its 2-byte scattered stores.  Lane 4 q + p of a group supplies the address of row q, columns 4 p .. 4 p + 3
+// (mapping checked on the device by benchmarks/probes/tr_read_probe.hip).  Needs all 64 lanes active.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <int DH, int DT0, int DT1>
+__device__ __forceinline__ void mma_reduce_rows_tr(f32x16 (&out)[DH / 32], const f32x16& w, const bf16_t* lds_row, int lane) {
+  const int h = lane >> 5, li = lane & 15, q = li >> 2, p = li & 3, half = (lane >> 4) & 1;
+  const bf16_t* base = lds_row + (4 * h + q) * Lds<bf16_t, DH>::RSTRIDE + 16 * half + 4 * p;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (bf16_t)w[8 * s + j];
+#pragma unroll
+    for (int dt = DT0; dt < DT1; ++dt) {
+      const bf16_t* zr = base + 16 * s * Lds<bf16_t, DH>::RSTRIDE + dt * 32;
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)zr);
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(zr + 8 * Lds<bf16_t, DH>::RSTRIDE));
+      union { s16x4_t s4[2]; bf16x8 v; } a;
+      a.s4[0] = lo; a.s4[1] = hi;
+      out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b, out[dt], 0, 0, 0);
+    }
+  }
+}
+
 // Per-lane fragments of this lane's own row (query / key) for the B operand of mma_reduce_d.
 template <typename T, int DH> struct RowFrag;
 template <int DH> struct RowFrag<float, DH> {

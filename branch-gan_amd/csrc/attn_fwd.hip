@@ -22,8 +22,8 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
   constexpr int NDT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* k_row = (T*)smem;                              // K tile, "row" layout
-  T* v_z = k_row + L::ROW_ELEMS;                    // V tile: bf16 "col" layout, fp32 padded "row" layout
-  int* red = (int*)(v_z + (sizeof(T) == 4 ? L::ROW_ELEMS : L::COL_ELEMS));
+  T* v_z = k_row + L::ROW_ELEMS;                    // V tile, row layout: read by columns (bf16: transposed LDS reads)
+  int* red = (int*)(v_z + L::ROW_ELEMS);
 
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -67,8 +67,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
   for (int kb = 0; kb < block_ctx; kb += ATT_TILE) {
     __syncthreads();  // previous tile fully consumed
     kreg.template store<true, false>(k_row, nullptr, tid);
-    if constexpr (sizeof(T) == 4) vreg.template store<true, false>(v_z, nullptr, tid);
-    else vreg.template store<false, true>(nullptr, v_z, tid);
+    vreg.template store<true, false>(v_z, nullptr, tid);
     __syncthreads();
     if (kb + ATT_TILE < block_ctx) {
       kreg.load(kt, sh.t_ss, kb + ATT_TILE, sh.S_text, tid);
@@ -105,7 +104,8 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+    if constexpr (sizeof(T) == 4) mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+    else mma_reduce_rows_tr<DH, 0, NDT>(o, s, v_z, lane);
   }
 
   // branch keys: the same branch point kq of every slot on this node's path (ancestors, then self)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
 template <typename T, int DH> struct SplitLds {
   using L = Lds<T, DH>;
   static constexpr int K_ELEMS = L::ROW_ELEMS;
-  static constexpr int V_ELEMS = sizeof(T) == 4 ? L::ROW_ELEMS : L::COL_ELEMS;
+  static constexpr int V_ELEMS = L::ROW_ELEMS;
   static constexpr size_t WAVE_BYTES = ((size_t)(K_ELEMS + V_ELEMS) * sizeof(T) + 15) / 16 * 16;
   static constexpr size_t MERGE_BYTES = (size_t)ATT_WAVES * (DH + 2) * ATT_TILE * sizeof(float);
   static constexpr size_t BYTES = (ATT_WAVES * WAVE_BYTES > MERGE_BYTES ? ATT_WAVES * WAVE_BYTES : MERGE_BYTES) + 64;
@@ -203,8 +203,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
     const int kb = t * ATT_TILE;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
     kreg.template store<true, false>(k_row, nullptr, lane);
-    if constexpr (sizeof(T) == 4) vreg.template store<true, false>(v_z, nullptr, lane);
-    else vreg.template store<false, true>(nullptr, v_z, lane);
+    vreg.template store<true, false>(v_z, nullptr, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // LDS is in order within a wave: stores land before the reads below
     if (t + ATT_WAVES < ntiles) {
       kreg.load(kt, sh.t_ss, kb + ATT_WAVES * ATT_TILE, sh.S_text, lane);
@@ -238,7 +237,8 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+    if constexpr (sizeof(T) == 4) mma_reduce_rows<T, DH, 0, NDT>(o, s, v_z, lane);
+    else mma_reduce_rows_tr<DH, 0, NDT>(o, s, v_z, lane);
   }
 
   // branch keys, path entries wave, wave + 4, ...
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
 
 size_t attn_fwd_lds_bytes(int dtype, int Dh) {
   if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
-  return (size_t)(ATT_TILE * (Dh + 8) + Dh * (ATT_TILE + 4)) * 2 + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 64;
 }
 
 int validate_attn_shape(const bg_attn_shape* s, const char* who) {
