@@ -176,10 +176,19 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
     for (int o = 32; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
     return t;
   };
-  auto next_tile = [&](int q0, int& reach) {             // first tile at or after q0 that reaches the keys, or >= R
+  // The reach of every query tile is worked out ONCE, up front (the tiles spread over the waves, their ctx_len loads in
+  // flight together): inside the sweep it decides which tile comes next, and a dependent global load there would put a full
+  // memory latency on every iteration's critical path.
+  int* reach_s = ctx_s + ATT_TILE;
+  for (int tq = wave; tq * ATT_TILE < R; tq += ATT_WAVES) {
     int n, kq, ctx;
+    const int reach = tile_reach(tq * ATT_TILE, n, kq, ctx);
+    if (lane == 0) reach_s[tq] = reach;
+  }
+  __syncthreads();
+  auto next_tile = [&](int q0, int& reach) {             // first tile at or after q0 that reaches the keys, or >= R
     for (; q0 < R; q0 += ATT_TILE) {
-      reach = tile_reach(q0, n, kq, ctx);
+      reach = reach_s[q0 / ATT_TILE];
       if (reach > key0_block) break;
     }
     return q0;
@@ -302,9 +311,10 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
-static size_t attn_dkv_lds_bytes(int dtype, int Dh) {
-  if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 3 * ATT_TILE * 4 + 64;
-  return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 3 * ATT_TILE * 4 + 64;
+static size_t attn_dkv_lds_bytes(int dtype, int Dh, int64_t n_queries) {
+  const size_t reach = (size_t)cdiv(n_queries, ATT_TILE) * 4;          // reach_s: one int per query tile
+  if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 3 * ATT_TILE * 4 + reach + 64;
+  return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 3 * ATT_TILE * 4 + reach + 64;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -378,7 +388,7 @@ static void launch_bwd(const AttnArgs& a, hipStream_t st) {
   const dim3 grid_q((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));
   const dim3 grid_k((unsigned)cdiv((int64_t)sh.S_text, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));
   const dim3 grid_s((unsigned)sh.n_slots, (unsigned)(sh.B * sh.H));
-  const size_t lq = attn_dq_lds_bytes(sh.dtype, sh.Dh), lk = attn_dkv_lds_bytes(sh.dtype, sh.Dh);
+  const size_t lq = attn_dq_lds_bytes(sh.dtype, sh.Dh), lk = attn_dkv_lds_bytes(sh.dtype, sh.Dh, (int64_t)sh.NQ * sh.K);
 #define BG_BWD_CASE(DH)                                                                                             \
   case DH: {                                                                                                        \
     set_lds_limit(branch_attn_bwd_dq_kernel<T, DH>, lq);                                                            \
