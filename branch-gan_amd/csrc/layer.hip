@@ -134,6 +134,7 @@ struct LnBwdArgs {
   float* partial;   // [gridDim.x][2 or 3][C]
   int64_t rows;
   int C;
+  int wave_lds;     // LDS holds one [2 or 3][C] region per wave (set by the launcher when that fits 64 KB)
 };
 
 // TY: dtype of dy;  TL: dtype of the low-precision copy of dx (ignored when dx_lp == nullptr);  COLSUM: also the column sums
@@ -205,6 +206,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
     }
   }
   // the four waves' column partials, added in wave order
+  constexpr int NP = COLSUM ? 3 : 2;
+  float* part = a.partial + (int64_t)blockIdx.x * NP * C;
+  if (a.wave_lds) {
+    // every wave leaves its partials in its own LDS region (vector stores, one barrier); the sum over the regions below
+    // runs in the same order as the wave-by-wave accumulation of the narrow-LDS path: identical bits
+    float* mine = lds + wave * NP * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (lane + 64 * i);
+      if (c < C) {
+        store4<float>(mine + c, dg[i]);
+        store4<float>(mine + C + c, db[i]);
+        if constexpr (COLSUM) store4<float>(mine + 2 * C + c, ds[i]);
+      }
+    }
+    __syncthreads();
+    for (int c = 4 * threadIdx.x; c < NP * C; c += 4 * 256) {
+      float acc[4], t[4];
+      load4<float>(lds + c, acc);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        load4<float>(lds + w * NP * C + c, t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += t[j];
+      }
+      store4<float>(part + c, acc);
+    }
+    return;
+  }
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -228,8 +258,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
     }
     __syncthreads();
   }
-  constexpr int NP = COLSUM ? 3 : 2;
-  float* part = a.partial + (int64_t)blockIdx.x * NP * C;
   for (int c = threadIdx.x; c < NP * C; c += 256) part[c] = lds[c];
 }
 
@@ -386,9 +414,12 @@ static void launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
 }
 
 template <typename TY, typename TL, bool COLSUM>
-static void launch_ln_bwd2(const LnBwdArgs& a, int G, hipStream_t st) {
+static void launch_ln_bwd2(const LnBwdArgs& a0, int G, hipStream_t st) {
   dim3 grid((unsigned)G), block(256);
-  const size_t lds = (size_t)(COLSUM ? 3 : 2) * a.C * sizeof(float);
+  LnBwdArgs a = a0;
+  size_t lds = (size_t)(COLSUM ? 3 : 2) * a.C * sizeof(float);
+  a.wave_lds = (4 * lds <= 65536 && a.C % 4 == 0) ? 1 : 0;
+  if (a.wave_lds) lds *= 4;
   const int nv = (int)cdiv(a.C, 256);
   if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2, COLSUM>), grid, block, lds, st, a);
   else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4, COLSUM>), grid, block, lds, st, a);
