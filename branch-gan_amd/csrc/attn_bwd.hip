@@ -161,9 +161,12 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int CPR = DH / VEC;                          // 16-byte chunks per row
   constexpr int PER = (ATT_TILE * CPR + 255) / 256;      // chunks per thread
   typedef typename TileRegs<T, DH, 256>::V Chunk;
-  Chunk q_reg[PER], do_reg[PER];
-  float lse_reg = 0.f, delta_reg = 0.f;
-  int ctx_reg = 0;
+  struct Stage {                                         // one gathered query tile on its way to LDS
+    Chunk q[PER], d[PER];
+    float lse = 0.f, delta = 0.f;
+    int ctx = 0;
+  };
+  Stage st_a, st_b;                                      // two tiles in flight: a gather has two iterations to land
   // max ctx over the queries of tile q0 (uniform over the workgroup); also leaves this lane's query in (n, kq, ctx)
   auto tile_reach = [&](int q0, int& n, int& kq, int& ctx) {
     const int rq = q0 + (lane & 31);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
     }
     return q0;
   };
-  auto gather = [&](int q0) {
+  auto gather = [&](int q0, Stage& st) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int c = tid + i * 256;
@@ -204,25 +207,28 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
       const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)nn * sh.q_sn + (int64_t)kk * sh.q_sk + d0;
       const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)nn * sh.o_sn + (int64_t)kk * sh.o_sk + d0;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { q_reg[i][j] = (T)0.0f; do_reg[i][j] = (T)0.0f; }
+      for (int j = 0; j < VEC; ++j) { st.q[i][j] = (T)0.0f; st.d[i][j] = (T)0.0f; }
       if (ok) {
-        q_reg[i] = *(const Chunk*)((const T*)a.q + qoff);
-        do_reg[i] = *(const Chunk*)((const T*)a.dout + ooff);
+        st.q[i] = *(const Chunk*)((const T*)a.q + qoff);
+        st.d[i] = *(const Chunk*)((const T*)a.dout + ooff);
       }
     }
     if (tid < ATT_TILE) {
       int n, kq;
-      tile_reach(q0, n, kq, ctx_reg);                    // wave 0 only: its own shuffle, same values
+      tile_reach(q0, n, kq, st.ctx);                     // wave 0 only: its own shuffle, same values
       const bool qv = q0 + tid < R;
       const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
-      lse_reg = qv ? a.lse[stat] : 0.f;
-      delta_reg = qv ? a.delta[stat] : 0.f;
+      st.lse = qv ? a.lse[stat] : 0.f;
+      st.delta = qv ? a.delta[stat] : 0.f;
     }
   };
-  int tile_ctx = 0, next_ctx = 0;
+  int tile_ctx = 0, next_ctx = 0, after_ctx = 0;
   int q0 = next_tile(0, tile_ctx);
-  if (q0 < R) gather(q0);
-  while (q0 < R) {
+  if (q0 < R) gather(q0, st_a);
+  int q1 = next_tile(q0 + ATT_TILE, next_ctx);
+  if (q1 < R) gather(q1, st_b);
+  // one iteration: the tile held in `st` goes to LDS, `st` is refilled with the tile after next, the tile is consumed
+  auto sweep = [&](Stage& st) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -232,26 +238,28 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          q_row_l[r * L::RSTRIDE + d0 + j] = q_reg[i][j];
-          do_row_l[r * L::RSTRIDE + d0 + j] = do_reg[i][j];
+          q_row_l[r * L::RSTRIDE + d0 + j] = st.q[i][j];
+          do_row_l[r * L::RSTRIDE + d0 + j] = st.d[i][j];
         }
       } else {
-        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = q_reg[i];      // one image: read by rows for S / dP, by columns
-        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = do_reg[i];    // (transposed LDS reads) for dV / dK
+        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = st.q[i];       // one image: read by rows for S / dP, by columns
+        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = st.d[i];      // (transposed LDS reads) for dV / dK
       }
     }
     if (tid < ATT_TILE) {
-      lse_s[tid] = lse_reg;
-      delta_s[tid] = delta_reg;
-      ctx_s[tid] = ctx_reg;  // 0 for invalid queries: masks everything
+      lse_s[tid] = st.lse;
+      delta_s[tid] = st.delta;
+      ctx_s[tid] = st.ctx;  // 0 for invalid queries: masks everything
     }
     __syncthreads();
-    const int q1 = next_tile(q0 + ATT_TILE, next_ctx);
-    if (q1 < R) gather(q1);
+    const int q2 = next_tile(q1 + ATT_TILE, after_ctx);
+    if (q2 < R) gather(q2, st);
     const int this_ctx = tile_ctx;
     q0 = q1;
+    q1 = q2;
     tile_ctx = next_ctx;
-    if (this_ctx <= key0_wave) continue;  // wave-uniform: nothing in this tile sees this wave's keys
+    next_ctx = after_ctx;
+    if (this_ctx <= key0_wave) return;  // wave-uniform: nothing in this tile sees this wave's keys
 
     f32x16 s, dp;
 #pragma unroll
@@ -273,6 +281,11 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dkv_kernel(AttnArgs a) {
       mma_reduce_rows_tr<DH, DT0, DT1>(dv, s, do_row_l, lane);
       mma_reduce_rows_tr<DH, DT0, DT1>(dk, dp, q_row_l, lane);
     }
+  };
+  while (q0 < R) {
+    sweep(st_a);
+    if (q0 >= R) break;
+    sweep(st_b);
   }
 
   if (kvalid) {
