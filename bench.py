@@ -147,7 +147,7 @@ def attention_forward_roofline(wl, device, dtype, reps=5):
 
 def adam_roofline(optims):
     """Roofline of bg_adam_step (adam_step_kernel), the hand-written kernel with the largest share of a step's GPU time
-    (profiles/r1_m_bench_c2_by_class.txt): two launches per step, one per model.  `optims` hold the (start, end) HIP events
+    (profiles/r1_n_bench_c2_by_class.txt): two launches per step, one per model.  `optims` hold the (start, end) HIP events
     branchgan.optim.ArenaAdam.step recorded around every launch INSIDE the timed region, on the stream it launched on.
     Algorithmic bytes per launch = 34 B per parameter slot of the arena (read p, g, m, v fp32; write p, m, v fp32, the bf16
     weight copy and the zeroed gradient), DESIGN.md."""
