@@ -47,10 +47,13 @@ class ReduceDesc(ctypes.Structure):
 SIGNATURES = {
     "bg_last_error": (ctypes.c_char_p, []),
     "bg_version": (c_i32, []),
+    "bg_build_id": (ctypes.c_char_p, []),
     "bg_device_arch": (c_i32, [ctypes.c_char_p, c_sz]),
     "bg_topn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "bg_topn_select": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),
+    "bg_topn_select_static": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp,
+                                      c_vp]),
     "bg_topp_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "bg_topp_select": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_softmax_stats_fwd": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
@@ -85,6 +88,22 @@ SIGNATURES = {
 _lib = None
 
 
+def source_build_id():
+    """sha256 over the library's sources in the order csrc/Makefile uses (None when the sources are not beside the .so)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    files = (sorted(glob.glob(os.path.join(csrc, "*.hip"))) + sorted(glob.glob(os.path.join(csrc, "*.h")))
+             + [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "branchgan.h"), os.path.join(csrc, "Makefile")])
+    if not all(os.path.exists(f) for f in files) or len(files) < 4:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:32]
+
+
 def lib():
     """Loads the shared library once.  Raises if it is not built (run __graft_entry__.build())."""
     global _lib
@@ -98,6 +117,11 @@ def lib():
             if fn is None:                  # calling it later raises AttributeError; tests/test_capi.py is strict
                 continue
             fn.restype, fn.argtypes = res, args
+        want = source_build_id()
+        have = handle.bg_build_id().decode() if hasattr(handle, "bg_build_id") else "<none>"
+        if want is not None and have != want and os.environ.get("BRANCHGAN_ALLOW_STALE_LIB") != "1":
+            raise RuntimeError(f"{LIB_PATH} is stale: built from sources {have}, the sources beside it hash to {want}; "
+                               "rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = handle
     return _lib
 

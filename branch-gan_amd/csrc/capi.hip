@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "../build/build_id.h"
 
 namespace bg {
 static thread_local char g_err[512] = "";
@@ -14,7 +15,8 @@ void set_error(const char* fmt, ...) {
 }  // namespace bg
 
 extern "C" const char* bg_last_error(void) { return bg::g_err; }
-extern "C" int bg_version(void) { return 1; }
+extern "C" int bg_version(void) { return 2; }
+extern "C" const char* bg_build_id(void) { return BG_BUILD_ID; }
 
 extern "C" int bg_device_arch(char* buf, size_t buf_len) {
   int dev = 0;

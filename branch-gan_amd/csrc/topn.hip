@@ -9,6 +9,7 @@
 // not below the threshold (≈ n·ln(V/n) times per wave); everything else costs one compare.  Items are
 // 64-bit composites (order-preserving key bits << 32 | ~index) so one integer compare gives the total
 // order "larger key first, NaN largest, equal keys by increasing index".  Waves merge through LDS by rank.
+#include <mutex>
 #include <type_traits>
 
 #include "topn_common.h"
@@ -256,29 +257,32 @@ extern "C" size_t bg_topn_workspace_bytes(int64_t rows, int64_t V, int n) {
   return splits > 1 ? (size_t)rows * splits * n * sizeof(u64) : 0;
 }
 
-extern "C" int bg_topn_select(const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
-                              const int64_t* row_map, const float* noise, int64_t noise_row_stride,
-                              const int64_t* blocked, int n_blocked, float blocked_value, int n, int64_t* out_ids,
-                              float* out_keys, void* workspace, size_t workspace_bytes, void* stream) {
-  BG_REQUIRE(scores && out_ids, "bg_topn_select: null scores/out_ids");
-  BG_REQUIRE(dtype == BG_F32 || dtype == BG_BF16, "bg_topn_select: dtype %d", dtype);
-  BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_topn_select: rows=%lld", (long long)rows);
-  BG_REQUIRE(V > 0 && V < (1ll << 31), "bg_topn_select: V=%lld", (long long)V);
-  BG_REQUIRE(n >= 1 && n <= BG_MAX_TOPN && n <= V, "bg_topn_select: n=%d must be in [1, min(%d, V)]", n, BG_MAX_TOPN);
-  BG_REQUIRE(score_row_stride >= V, "bg_topn_select: score_row_stride < V");
-  BG_REQUIRE(!noise || noise_row_stride >= V, "bg_topn_select: noise_row_stride < V");
-  BG_REQUIRE(n_blocked >= 0 && n_blocked <= BG_MAX_BLOCKED && (n_blocked == 0 || blocked), "bg_topn_select: n_blocked=%d", n_blocked);
+// One body for both entry points: `partial` is the caller's workspace (bg_topn_select) or this device's copy of the
+// file-scope scratch array (bg_topn_select_static); nothing here allocates or synchronises.
+static int topn_launch(const char* who, const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
+                       const int64_t* row_map, const float* noise, int64_t noise_row_stride, const int64_t* blocked,
+                       int n_blocked, float blocked_value, int n, int64_t* out_ids, float* out_keys, u64* partial,
+                       size_t partial_bytes, void* stream) {
+  BG_REQUIRE(scores && out_ids, "%s: null scores/out_ids", who);
+  BG_REQUIRE(dtype == BG_F32 || dtype == BG_BF16, "%s: dtype %d", who, dtype);
+  BG_REQUIRE(rows > 0 && rows < (1ll << 31), "%s: rows=%lld", who, (long long)rows);
+  BG_REQUIRE(V > 0 && V < (1ll << 31), "%s: V=%lld", who, (long long)V);
+  BG_REQUIRE(n >= 1 && n <= BG_MAX_TOPN && n <= V, "%s: n=%d must be in [1, min(%d, V)]", who, n, BG_MAX_TOPN);
+  BG_REQUIRE(score_row_stride >= V, "%s: score_row_stride < V", who);
+  BG_REQUIRE(!noise || noise_row_stride >= V, "%s: noise_row_stride < V", who);
+  BG_REQUIRE(n_blocked >= 0 && n_blocked <= BG_MAX_BLOCKED && (n_blocked == 0 || blocked), "%s: n_blocked=%d", who, n_blocked);
   const int splits = choose_splits(rows, V);
   TopnArgs a;
   a.scores = scores; a.row_map = row_map; a.noise = noise; a.blocked = blocked;
   a.V = V; a.score_stride = score_row_stride; a.noise_stride = noise_row_stride;
   a.seg_len = cdiv(cdiv(V, splits), 2048) * 2048;
   a.n = n; a.n_blocked = n_blocked; a.splits = splits; a.blocked_value = blocked_value;
-  a.out_ids = out_ids; a.out_keys = out_keys; a.partial = (u64*)workspace;
+  a.out_ids = out_ids; a.out_keys = out_keys; a.partial = partial;
   if (splits > 1) {
     size_t need = (size_t)rows * splits * n * sizeof(u64);
-    if (!workspace || workspace_bytes < need) {
-      set_error("bg_topn_select: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (!partial || partial_bytes < need) {
+      set_error("%s: %s holds %zu bytes, rows=%lld x splits=%d x n=%d partial items need %zu", who,
+                partial ? "the partial buffer" : "a NULL partial buffer", partial_bytes, (long long)rows, splits, n, need);
       return BG_ERR_WORKSPACE;
     }
   }
@@ -291,10 +295,60 @@ extern "C" int bg_topn_select(const void* scores, int dtype, int64_t rows, int64
     if (noise) hipLaunchKernelGGL((topn_partial_kernel<bf16_t, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((topn_partial_kernel<bf16_t, false>), grid, block, 0, st, a);
   }
-  BG_CHECK_LAUNCH("bg_topn_select");
+  BG_CHECK_LAUNCH(who);
   if (splits > 1) {
-    hipLaunchKernelGGL(topn_merge_kernel, dim3((unsigned)rows), block, 0, st, (const u64*)workspace, splits, n, out_ids, out_keys);
-    BG_CHECK_LAUNCH("bg_topn_select(merge)");
+    hipLaunchKernelGGL(topn_merge_kernel, dim3((unsigned)rows), block, 0, st, (const u64*)partial, splits, n, out_ids, out_keys);
+    BG_CHECK_LAUNCH(who);
   }
   return BG_OK;
+}
+
+extern "C" int bg_topn_select(const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
+                              const int64_t* row_map, const float* noise, int64_t noise_row_stride,
+                              const int64_t* blocked, int n_blocked, float blocked_value, int n, int64_t* out_ids,
+                              float* out_keys, void* workspace, size_t workspace_bytes, void* stream) {
+  return topn_launch("bg_topn_select", scores, dtype, rows, V, score_row_stride, row_map, noise, noise_row_stride, blocked,
+                     n_blocked, blocked_value, n, out_ids, out_keys, (u64*)workspace, workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing (include/branchgan.h: bg_topn_select_static) ----
+// The per-(row, split) partial lists of topn_partial_kernel live in a file-scope device array instead of a caller
+// workspace.  In host code the array's NAME is only a stand-in for the symbol: each GPU holds its own copy at its own
+// address, which hipGetSymbolAddress returns once per device (with that device current); host code uses that pointer.
+static __device__ __align__(256) u64 scratch[BG_TOPN_STATIC_ITEMS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+u64* g_scratch_ptr[kMaxDevices];     // per device: address of ITS copy of `scratch` (null until the first call on it)
+}  // namespace
+
+extern "C" int bg_topn_select_static(const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
+                                     const int64_t* row_map, const float* noise, int64_t noise_row_stride,
+                                     const int64_t* blocked, int n_blocked, float blocked_value, int n, int64_t* out_ids,
+                                     float* out_keys, void* stream) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("bg_topn_select_static: no current HIP device (or device index %d >= %d)", dev, kMaxDevices);
+    return BG_ERR_LAUNCH;
+  }
+  u64* ptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ptr = g_scratch_ptr[dev];
+    if (!ptr) {
+      void* sym = nullptr;
+      hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+      if (e != hipSuccess || !sym) {
+        set_error("bg_topn_select_static: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+        return BG_ERR_LAUNCH;
+      }
+      ptr = g_scratch_ptr[dev] = (u64*)sym;
+    }
+  }
+  // the partial kernel writes every slot of a (row, split) list it hands to the merge kernel (it clears the list before the
+  // rank-merge), so the last call's contents never reach this call's result and no memset is needed
+  return topn_launch("bg_topn_select_static", scores, dtype, rows, V, score_row_stride, row_map, noise, noise_row_stride,
+                     blocked, n_blocked, blocked_value, n, out_ids, out_keys, ptr,
+                     (size_t)BG_TOPN_STATIC_ITEMS * sizeof(u64), stream);
 }

@@ -38,6 +38,9 @@ extern "C" {
 
 const char* bg_last_error(void);
 int bg_version(void);
+/* sha256 (first 32 hex digits) over the sources this library was built from (every .hip and .h under csrc, this
+ * header, the Makefile): the host side compares it with the sources beside it and refuses a stale build. */
+const char* bg_build_id(void);
 /* gfx arch string of the current device ("gfx950"), into buf; returns BG_OK or BG_ERR_LAUNCH. */
 int bg_device_arch(char* buf, size_t buf_len);
 
@@ -62,6 +65,24 @@ int bg_topn_select(const void* scores, int dtype, int64_t rows, int64_t V, int64
                    const int64_t* blocked, int n_blocked, float blocked_value,
                    int n, int64_t* out_ids, float* out_keys,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same selection for callers that cannot allocate device memory or bring a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference: it exists for those
+ * callers only.  The per-(row, split) partial lists live in a file-scope device array of the library,
+ * BG_TOPN_STATIC_ITEMS x 8 bytes = 1 MiB that every GPU the library runs on holds until the process ends; the call makes no
+ * hipMalloc / hipFree and calls no allocating routine.  Arguments and results are those of bg_topn_select (bit-identical
+ * ids and keys).  Limit: when rows < 2048 the row is split over `splits` = min(ceil(2048 / rows), V / 4096, 16)
+ * workgroups and rows x splits x n must be <= BG_TOPN_STATIC_ITEMS (always true for n <= 32), otherwise
+ * BG_ERR_WORKSPACE and a message with the numbers; rows >= 2048 needs no partial lists.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them.  The first call on each
+ * device looks the array's address up (hipGetSymbolAddress); make that first call outside a graph capture.
+ */
+#define BG_TOPN_STATIC_ITEMS 131072
+int bg_topn_select_static(const void* scores, int dtype, int64_t rows, int64_t V, int64_t score_row_stride,
+                          const int64_t* row_map,
+                          const float* noise, int64_t noise_row_stride,
+                          const int64_t* blocked, int n_blocked, float blocked_value,
+                          int n, int64_t* out_ids, float* out_keys, void* stream);
 
 /* Top-p filter + exponential race (SamplingStrategies.py:161-187, top_p_sampling):
  * sort descending, cumulative sum, keep sorted position i iff cum[i+1] <= p (the reference's shift),
