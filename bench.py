@@ -221,6 +221,10 @@ def main():
     if os.environ.get("BRANCHGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BRANCHGAN_BENCH_WATCHDOG"]), exit=True)
+        probe = os.path.join(ROOT, "benchmarks", "probes", "libsegvbt.so")      # native stacks of every thread 3 s earlier
+        if os.path.exists(probe):
+            import ctypes
+            ctypes.CDLL(probe).install_all_thread_dump(int(float(os.environ["BRANCHGAN_BENCH_WATCHDOG"])) - 3)
 
     from branchgan import ops, training
     tuned = (not args.no_tuned_gemm) and training.use_tuned_gemms()

@@ -93,15 +93,17 @@ def sampling(rows, V):
         report(f"TOP_P p={p} n=4 rows={rows} V={V}", ms, 2 * rows * V * e + rows * 4 * 12)
     ids = torch.randint(0, V, (rows, 2), device="cuda", generator=g)
     for dt, es in ((torch.float32, 4), (torch.bfloat16, 2)):
-        x = logits.to(dt).requires_grad_(True)
+        # a LEAF of its own: `logits.to(float32)` is logits itself, so requires_grad_ on it would make the bf16 copy of the next
+        # iteration a non-leaf whose grad_fn lives on the default stream - autograd then pulls the null stream into the capture
+        # and ROCm 7.2's hipStreamEndCapture segfaults on it (benchmarks/probes/graph_anomalies.py segv-nonleaf)
+        x = logits.detach().to(dt, copy=True).requires_grad_(True)
         ms = timeit(lambda: ops.softmax_stats(x.detach(), ids))
         report(f"softmax_stats_fwd rows={rows} V={V} {dt}", ms, rows * V * es)
         def make_bwd(x=x):
             lse, lp = ops.softmax_stats(x, ids)
             gl, gp = torch.randn_like(lse), torch.randn_like(lp)
             return lambda: torch.autograd.grad((lse, lp), x, (gl, gp), retain_graph=True)
-        # (bf16 at rows <= 1024: capturing this backward crashed hipGraph instantiation on ROCm 7.2 - timed eagerly instead)
-        ms = timeit_graphed(make_bwd) if small and dt == torch.float32 else globals()['timeit'](make_bwd())
+        ms = timeit_graphed(make_bwd) if small else globals()['timeit'](make_bwd())
         report(f"softmax_stats_bwd rows={rows} V={V} {dt}", ms, 2 * rows * V * es)
     # evaluation metrics: one read of the probabilities per row (the reference: three full sorts of the same tensor)
     labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
@@ -153,12 +155,16 @@ def attention(B, H, Dh, S, K, depth, dtype):
 
 
 if __name__ == "__main__":
+    if os.environ.get("BRANCHGAN_SEGV_BT"):      # probe: native backtrace on SIGSEGV (benchmarks/probes/segv_backtrace.cpp)
+        import ctypes
+        ctypes.CDLL(os.path.join(ROOT, "benchmarks", "probes", "libsegvbt.so")).install_segv_backtrace()
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all", choices=["all", "sampling", "attention", "metrics"])
     ap.add_argument("--rows", type=int, default=8192)
     a = ap.parse_args()
     if a.what in ("all", "sampling"):
-        sampling(a.rows, 50304)
+        if not os.environ.get("BRANCHGAN_SWEEP_SMALL_ONLY"):
+            sampling(a.rows, 50304)
         sampling(256, 50257)
     if a.what == "metrics":
         g = torch.Generator(device="cuda").manual_seed(2)

@@ -82,6 +82,8 @@ SIGNATURES = {
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
     "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),
+    "bg_graph_node_census": (c_i32, [c_vp] + [ctypes.POINTER(c_i32)] * 4),
+    "bg_graph_replace_memset_nodes": (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     "bg_rl_loss_bwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp, c_vp, c_vp]),
 }
 

@@ -8,52 +8,103 @@ The gradient all-reduce (RCCL) and the optimizer steps stay outside the graph, s
 The reference has no counterpart (it is eager PyTorch); results are identical to the eager step by construction.
 """
 import copy
+import ctypes
 import os
 
 import torch
 
+from . import _capi as C
 from . import ops
 from . import fused
+from .sampling import SamplingTechniques
+
+
+def new_graph():
+    """A CUDAGraph whose captured hipGraph is kept until `finalize_graph` has cleaned it (instantiation is deferred)."""
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def finalize_graph(graph):
+    """Replaces every MEMSET node of a freshly captured graph by a fill-kernel node, then instantiates it.
+
+    Cause (measured, benchmarks/probes/graph_anomalies.py, profiles/r2_a_graph_anomalies.txt): on ROCm 7.2.0 a memset node - what a
+    captured hipMemsetAsync becomes - clears its destination on the FIRST replay and fills it with garbage from the second
+    on.  ATen's multi-block reductions clear their arrival counters with such a call before every launch, so from the second
+    replay no workgroup sees itself arrive last and the result is never written: the stale / NaN bias gradients round 1
+    met on the module-by-module path (the fused path computes those sums in this library's kernels, which use no memset).
+    Returns (nodes, kernel nodes, memset nodes replaced, memcpy nodes)."""
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    c = [ctypes.c_int() for _ in range(4)]
+    C.check(C.lib().bg_graph_node_census(raw, *[ctypes.byref(x) for x in c]), "bg_graph_node_census")
+    n = ctypes.c_int()
+    C.check(C.lib().bg_graph_replace_memset_nodes(raw, ctypes.byref(n)), "bg_graph_replace_memset_nodes")
+    if n.value != c[2].value:
+        raise RuntimeError(f"finalize_graph: {c[2].value} memset nodes, {n.value} replaced")
+    graph.instantiate()
+    return c[0].value, c[1].value, n.value, c[3].value
 
 
 def _sync_after_replay():
-    """Multi-rank runs wait on the host for a replayed graph before they issue the gradient all-reduce that depends on it.
-    Measured on MI355X / ROCm 7.2 with 2 ranks (gloo, one GPU): a collective enqueued while the graph it waits for is still
-    executing can deadlock (the collective's stream wait never fires; eager launches and finished graphs are fine).  The
-    all-reduce + Adam of the generator still overlap the discriminator's backward graph, which is launched right after; the
-    cost is one host round trip (~0.1 ms) per graph.  BRANCHGAN_GRAPH_SYNC=0/1 overrides."""
+    """Whether step() waits on the host for a replayed graph before it issues the gradient all-reduce.
+
+    History: round 1 saw two gloo ranks sharing one GPU stall in `arena.wait()` and blamed a collective enqueued behind a
+    RUNNING graph.  Round 2 put native stacks on it (benchmarks/probes/hang_probe.sh, profiles/r2_a_graph_anomalies.txt): the same
+    stall happens with NO graph at all (eager train_step, GPT-2-small arenas of ~1 GB in 64 MB buckets; tiny models pass) -
+    one rank's gloo workers sit in hipStreamSynchronize (gloo stages every bucket through pinned host memory from its own
+    worker threads), the other rank's wait in TCP recv for them.  It is gloo's host-staged CUDA path under two processes on
+    one device, not graph replay, and a host sync after a replay neither causes nor cures it.  RCCL collectives are
+    stream-ordered device work, so the production path (backend nccl) does not sync; gloo (host-driven anyway) keeps the
+    sync so its worker threads never poll a stream a graph is still running on.  BRANCHGAN_GRAPH_SYNC=0/1 overrides."""
     env = os.environ.get("BRANCHGAN_GRAPH_SYNC")
     if env is not None:
         return env == "1"
+    dist = torch.distributed
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo" and dist.get_world_size() > 1
+
+
+def _multi_rank():
     from .training import REHEARSE_RCCL
-    return torch.distributed.is_available() and torch.distributed.is_initialized() and (torch.distributed.get_world_size() > 1 or REHEARSE_RCCL)
+    dist = torch.distributed
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or REHEARSE_RCCL)
 
 
-def _require_fused_path(model, example_ids):
-    """Graph replay is supported for models on the fused block path only.  On the module-by-module path the bias gradients
-    come from ATen's multi-block reductions, and those return NaNs in a few columns from the SECOND replay of a captured
-    graph (measured: GPT-2 small and Pythia-70M at the BASELINE shapes, bf16 autocast, ROCm 7.2 / torch 2.10; the same
-    step is fine eagerly, in fp32, and at the tiny test shapes where the reduction fits one workgroup).  The fused path
-    computes those gradients in this library's kernels.  BRANCHGAN_GRAPH_UNFUSED=1 overrides (debugging)."""
-    if os.environ.get("BRANCHGAN_GRAPH_UNFUSED") == "1":
-        return
-    from . import models
-    for name, lm in (("generator", model.generator.generator), ("discriminator", model.discriminator.nonResidualModel)):
-        if not models._fused_eligible(lm, example_ids, None, None, False):
-            raise NotImplementedError(
-                f"GraphedTrainStep: the {name} does not run on the fused block path (BRANCHGAN_FUSED=0, dropout, a hidden size "
-                "that is not a multiple of 8 or above 4096, a head size outside {32, 64, 128, 256}, non-fp32 parameters): "
-                "use the eager branchgan.training.train_step for it")
+def _rule_strategies(rules):
+    for r in rules:
+        yield r.samplingStrategy
+        if r.firstBeamSamplingStrategy is not None:
+            yield r.firstBeamSamplingStrategy
+
+
+def _check_rules(rules):
+    """A captured step replays the same launches with the same arguments.  TOP_K is a pure function of the logits; the
+    exponential-race techniques read their noise from a tensor, which step() refreshes in place before every replay
+    (`_static_noise`).  RANDOM / SAMPLE / EPSILON_* draw from host-side or global generators inside the sampling call
+    (SamplingStrategies.py:133-146,190-194,217-233): captured, they would replay one frozen draw - refused."""
+    T = SamplingTechniques
+    ok = {T.TOP_K, T.DEBUG_GRAB_FIRST_IDS, T.SAMPLE_NO_REPLACEMENT, T.INVERSE_TOP_K_SAMPLE_NO_REPLACEMENT, T.TOP_P_SAMPLE_NO_REPLACEMENT}
+    for strat in _rule_strategies(rules):
+        strat = strat if isinstance(strat, T) else T(int(getattr(strat, "value", strat)))
+        if strat not in ok:
+            raise NotImplementedError(f"GraphedTrainStep: sampling technique {strat.name} draws random numbers inside the sampling call; "
+                                      "a HIP graph would replay one frozen draw.  Use the eager branchgan.training.train_step for it")
+    for r in rules:
+        if 'noise_level' in (r.samplingParams or {}) or 'noise_level' in (r.firstBeamSamplingParams or {}):
+            raise NotImplementedError("GraphedTrainStep: 'noise_level' (Dirichlet noise from torch's global generator) cannot be captured")
 
 
 class GraphedTrainStep:
+    """`warmup` eager steps lay out the arenas, caches and workspaces; they run on `example_ids` and, unless
+    restore_after_warmup=False, parameters, optimizer state (moments, step counts) and LR schedulers are put back to what
+    they were before, so building a graphed step does not train the model."""
+
     def __init__(self, model, sampleConf, generatorOptim, discriminatorOptim, example_ids, numUpdateSamples=9999,
-                 reinforcementLearningConfig=None, amp_dtype=None, warmup=3):
+                 reinforcementLearningConfig=None, amp_dtype=None, warmup=3, restore_after_warmup=True):
         self.model, self.g_opt, self.d_opt = model, generatorOptim, discriminatorOptim
         self.rl, self.n_update, self.amp_dtype = reinforcementLearningConfig, numUpdateSamples, amp_dtype
         self.src_conf = sampleConf
         dev = example_ids.device
-        _require_fused_path(model, example_ids)
+        _check_rules(sampleConf.rules)
+        self.depth = len(sampleConf.rules)
         self.static_ids = example_ids.clone()
         K = sampleConf.numSampleSequences or example_ids.shape[1]
         self.static_sparse = torch.zeros(K, dtype=torch.long, device=dev)
@@ -62,39 +113,113 @@ class GraphedTrainStep:
         self.graph = None
         self.losses = None
         self._sync = _sync_after_replay()
-        self._defer_d = self._sync if os.environ.get("BRANCHGAN_DEFER_D") is None else os.environ["BRANCHGAN_DEFER_D"] == "1"
+        self._defer_d = _multi_rank() if os.environ.get("BRANCHGAN_DEFER_D") is None else os.environ["BRANCHGAN_DEFER_D"] == "1"
         self._pending_d = None
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
+        # exponential noise of the race techniques: persistent tensors, one per sampling call of a step, refreshed before a replay
+        self._noise, self._noise_cursor, self._user_noise = [], 0, model.noise_fn
         self._refresh_sparse(example_ids)
         side = torch.cuda.Stream(device=dev)
+        self.stream = side
+        self._own_stream = os.environ.get("BRANCHGAN_REPLAY_STREAM", "0") == "1"
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # eager warm-up: builds arenas, caches, workspaces
-            for i in range(warmup):
-                self._forward_backward()
-                self._finish(i)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
-        # three graphs: [generator forward], [discriminator forward + losses + generator backward], [discriminator backward];
-        # see step() for what runs between them.
-        self.graph_g = torch.cuda.CUDAGraph()
-        self.graph = torch.cuda.CUDAGraph()
-        self.graph_d = torch.cuda.CUDAGraph()
-        fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
-        # ONE stream for the warm-up and all three captures: autograd runs every AccumulateGrad node on the stream it was created
-        # on, and a node created while one graph is captured must not end up on another graph's stream
-        with torch.cuda.graph(self.graph_g, stream=side, capture_error_mode="thread_local"):   # collective backends run helper threads
-            with self._autocast():
-                self.gen_state = self.model._generatorForward(self.static_ids, self.conf)
-        with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
-            self.losses = self._forward(self.gen_state)
-            self.losses[1][self.g_opt.lossKey].backward()
-        with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
-            self.losses[0][self.d_opt.lossKey].backward()
-        ops.TIMING = timing
+        if warmup < 1:
+            raise ValueError("GraphedTrainStep: at least one warm-up step (it lays out the arenas, workspaces and noise tensors)")
+        saved = self._snapshot() if restore_after_warmup else None
+        model.noise_fn = self._static_noise
+        try:
+            import warnings
+            with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:   # eager warm-up: builds arenas, caches, workspaces
+                warnings.simplefilter("always")
+                for i in range(warmup):
+                    self._refresh_noise()
+                    self._forward_backward()
+                    self._finish(i)
+                if saved is not None:
+                    self._restore(saved)
+            for w in caught:
+                # autograd keeps a parameter's AccumulateGrad node alive, bound to the stream it was created on, for as long as an
+                # autograd graph refers to it.  A capture would then make the capture stream synchronise with that other stream;
+                # when it is the default stream, ROCm 7.2's hipStreamEndCapture segfaults (graph_anomalies.py segv-nonleaf)
+                if "AccumulateGrad node's stream does not match" in str(w.message):
+                    raise RuntimeError("GraphedTrainStep: an autograd graph of this model built on another stream is still alive (losses or "
+                                       "outputs of an earlier eager step): drop those references before building the graphed step")
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
+            # three graphs: [generator forward], [discriminator forward + losses + generator backward], [discriminator backward];
+            # see step() for what runs between them.
+            self.graph_g, self.graph, self.graph_d = new_graph(), new_graph(), new_graph()
+            fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
+            # ONE stream for the warm-up and all three captures: autograd runs every AccumulateGrad node on the stream it was created
+            # on, and a node created while one graph is captured must not end up on another graph's stream.  (A node that lives on the
+            # DEFAULT stream is worse: autograd then pulls the null stream into the capture and ROCm 7.2's hipStreamEndCapture
+            # segfaults walking the capture's streams - benchmarks/probes/graph_anomalies.py segv-nonleaf.)
+            self._noise_cursor = 0
+            with torch.cuda.graph(self.graph_g, stream=side, capture_error_mode="thread_local"):   # collective backends run helper threads
+                with self._autocast():
+                    self.gen_state = self.model._generatorForward(self.static_ids, self.conf)
+            # the sampled branch tokens of every tree node, (B, K) each, valid after a replay of graph_g (the second graph clears the tree)
+            self.sampled_ids = [n.ids for n in self.gen_state[0].getSubNodes()]
+            with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
+                self.losses = self._forward(self.gen_state)
+                self.losses[1][self.g_opt.lossKey].backward()
+            with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
+                self.losses[0][self.d_opt.lossKey].backward()
+            ops.TIMING = timing
+        finally:
+            model.noise_fn = self._user_noise
+        self.census = [finalize_graph(g) for g in (self.graph_g, self.graph, self.graph_d)]     # memset nodes -> fill kernels
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
         self.g_opt.arena.zero()
         self.d_opt.arena.zero()
+
+    # ---- noise of the exponential-race techniques -------------------------------------------------------------------------
+    def _static_noise(self, shape, device):
+        """model.noise_fn while this object builds: the i-th sampling call of a step always gets the i-th persistent tensor."""
+        i, self._noise_cursor = self._noise_cursor, self._noise_cursor + 1
+        if i == len(self._noise):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("GraphedTrainStep: a sampling call asked for noise that the warm-up steps never drew")
+            self._noise.append(torch.empty(tuple(shape), dtype=torch.float32, device=device))
+            self._fill_noise(self._noise[i])
+        if tuple(self._noise[i].shape) != tuple(shape):
+            raise RuntimeError(f"GraphedTrainStep: noise request {i} changed shape {tuple(self._noise[i].shape)} -> {tuple(shape)}")
+        return self._noise[i]
+
+    def _fill_noise(self, t):
+        if self._user_noise is not None:                     # an injected noise source (tests): asked eagerly, copied in place
+            t.copy_(self._user_noise(tuple(t.shape), t.device))
+        else:                                                # e = -log(U): Exp(1), what SampleBuffer.py:28 draws (fresh, not rolled)
+            t.exponential_()
+
+    def _refresh_noise(self):
+        self._noise_cursor = 0
+        for t in self._noise:
+            self._fill_noise(t)
+
+    # ---- warm-up bookkeeping ------------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        opts = (self.g_opt, self.d_opt)
+        return {"params": [p.detach().clone() for p in self.model.parameters()],
+                "optim": [copy.deepcopy(o.optimizer.state_dict()) for o in opts],
+                "sched": [copy.deepcopy(o.scheduler.state_dict()) if o.scheduler is not None else None for o in opts]}
+
+    def _restore(self, saved):
+        with torch.no_grad():
+            for p, v in zip(self.model.parameters(), saved["params"]):
+                p.copy_(v)
+        for o, st, sc in zip((self.g_opt, self.d_opt), saved["optim"], saved["sched"]):
+            opt = o.optimizer
+            if hasattr(opt, "reset_state"):                  # optim.ArenaAdam: moments and step count live in its arenas
+                opt.reset_state()
+            opt.load_state_dict(st)
+            if hasattr(opt, "refresh_weight_copies"):
+                opt.refresh_weight_copies()
+            if sc is not None:
+                o.scheduler.load_state_dict(sc)
+            o.arena.zero()
+        fused.invalidate_weights()
 
     def _refresh_sparse(self, ids):
         src = self.src_conf
@@ -136,7 +261,26 @@ class GraphedTrainStep:
             self.d_opt.finish(self._pending_d)
             self._pending_d = None
 
-    def step(self, inputIDs, stepCounter):
+    def step(self, inputIDs, stepCounter, updateGen=True, updateDisc=True, sampleConf=None):
+        """updateGen / updateDisc: the update schedule of TrainingLoop.py:129-134.  A model that is not updated this step still runs
+        (its backward is part of the captured graphs) and its gradients are discarded, which equals skipping its
+        performUpdateStep when gradAccum == 1 (refused otherwise).  sampleConf, when given, must have the captured depth."""
+        if sampleConf is not None and len(sampleConf.rules) != self.depth:
+            raise ValueError(f"GraphedTrainStep was captured at depth {self.depth}; got a sampling config of depth {len(sampleConf.rules)} "
+                             "(capture one GraphedTrainStep per depth: training.efficentTrainingLoop(useGraphs=True) does)")
+        for flag, opt in ((updateGen, self.g_opt), (updateDisc, self.d_opt)):
+            if not flag and opt.gradAccum != 1:
+                raise NotImplementedError("GraphedTrainStep: skipping a model's update needs gradAccum == 1")
+        if not self._own_stream:
+            return self._step(inputIDs, stepCounter, updateGen, updateDisc)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self._step(inputIDs, stepCounter, updateGen, updateDisc)
+        cur.wait_stream(self.stream)
+        return out
+
+    def _step(self, inputIDs, stepCounter, updateGen=True, updateDisc=True):
         """One train step: returns the (static) loss dicts; GanSetup.py:249-256's NaN guard is evaluated on the device and
         raised by check_nan() (one host sync when the caller chooses, not one per loss key per step).
 
@@ -147,19 +291,24 @@ class GraphedTrainStep:
         running beside a replaying graph costs 0.8 ms per step more than it hides."""
         self.static_ids.copy_(inputIDs, non_blocking=True)
         self._refresh_sparse(inputIDs)
+        self._refresh_noise()
         self.graph_g.replay()                              # generator forward
         self._finish_pending()                             # D's all-reduce of the last step is done by now: its Adam step
         self.graph.replay()                                # discriminator forward + losses + generator backward
         if self._sync:
             torch.cuda.current_stream().synchronize()
         d, g = self.losses
-        g_stepped = self._reduce(self.g_opt, stepCounter)
+        if not updateGen:
+            self.g_opt.arena.zero()
+        g_stepped = updateGen and self._reduce(self.g_opt, stepCounter)
         self.graph_d.replay()                              # discriminator backward, G's all-reduce behind it
         if self._sync:
             torch.cuda.current_stream().synchronize()
         self.nan_flag |= torch.isnan(g['loss'].detach())
         self.g_opt.finish(g_stepped)
-        d_stepped = self._reduce(self.d_opt, stepCounter)
+        if not updateDisc:
+            self.d_opt.arena.zero()
+        d_stepped = updateDisc and self._reduce(self.d_opt, stepCounter)
         if self._defer_d:
             self._pending_d = d_stepped
         else:

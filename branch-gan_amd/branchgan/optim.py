@@ -33,6 +33,7 @@ class ArenaAdam(torch.optim.Optimizer):
         self.grad_arena = None      # branchgan.training.GradArena, set by bind()
         self.param_arena = self.exp_avg = self.exp_avg_sq = self.lowp_arena = None
         self._outside = []
+        self._pending_state = None  # a state dict loaded before the arenas exist: copied in by _build
         self.timing = None          # a list: step() appends (start, end) HIP events recorded around its launch (bench.py)
 
     def bind(self, grad_arena):
@@ -57,10 +58,14 @@ class ArenaAdam(torch.optim.Optimizer):
         self.param_arena = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
             for p, off in zip(ga.params, ga.offsets):
                 view = self.param_arena[off:off + p.numel()].view(p.shape)
                 view.copy_(p.detach())
+                # the old storage goes back to its allocation stream's pool the moment p.data is re-pointed: tell the
+                # allocator that THIS stream still reads it (a no-op when this is the stream it was allocated on)
+                p.data.record_stream(cur)
                 p.data = view
         inside = {id(p) for p in ga.params}
         self._outside = [p for p in self.param_groups[0]['params'] if id(p) not in inside]
@@ -69,6 +74,23 @@ class ArenaAdam(torch.optim.Optimizer):
             for p, off in zip(ga.params, ga.offsets):
                 fused.pin_weight_copy(p, self.lowp_arena[off:off + p.numel()].view(p.shape), self)
         fused.invalidate_weights()
+        if self._pending_state:
+            self._copy_state_in()
+
+    def ensure_built(self):
+        """Lays the arenas out now, on the caller's stream (training.OptimizerWrapper calls this right after the first
+        backward, before any work moves to a side stream)."""
+        if self.param_arena is None and self.grad_arena is not None and self.grad_arena.arena is not None:
+            self._build()
+
+    def reset_state(self):
+        """Back to a freshly built optimizer: zero moments, step count 0 (the arenas and the parameter views stay)."""
+        self.steps = 0
+        self._pending_state = None
+        if self.exp_avg is not None:
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+        self.state.clear()
 
     def refresh_weight_copies(self):
         """After parameters were changed by hand (load_state_dict, .data edits): re-round the low-precision copies."""
@@ -118,11 +140,18 @@ class ArenaAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """torch.optim.Adam's layout.  Before the first step (the resume flow of SpawnedExperiment.py:27-34: build the
+        optimizer, load its start weights, then train) the arenas do not exist yet: the state is kept and copied in when
+        the first step lays them out."""
         super().load_state_dict(state_dict)
         if not self.state:
             return
         if self.param_arena is None:
-            raise RuntimeError("ArenaAdam.load_state_dict: run one step first (the arenas are laid out by the first step)")
+            self._pending_state = True
+            return
+        self._copy_state_in()
+
+    def _copy_state_in(self):
         with torch.no_grad():
             for p, off in zip(self.grad_arena.params, self.grad_arena.offsets):
                 st = self.state.get(p)
@@ -131,4 +160,5 @@ class ArenaAdam(torch.optim.Optimizer):
                     self.exp_avg[sl].view(p.shape).copy_(st['exp_avg'])
                     self.exp_avg_sq[sl].view(p.shape).copy_(st['exp_avg_sq'])
                     self.steps = int(float(st['step']))
+        self._pending_state = None
         self.state.clear()

@@ -148,6 +148,10 @@ class OptimizerWrapper:
     def reduce_async(self):
         """Starts the gradient all-reduce of an optimizer step.  The mean over ranks is either taken here or, for an
         optimizer that says so, folded into its update."""
+        if self.arena.arena is None:
+            self.arena._build()
+        if hasattr(self.optimizer, "ensure_built"):
+            self.optimizer.ensure_built()          # arenas laid out on the caller's stream, before any side-stream work
         folds = getattr(self.optimizer, "folds_grad_scale", False)
         if folds:
             world = dist.get_world_size(self.arena.group) if dist.is_initialized() else 1
@@ -310,12 +314,26 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
     schedule decides which model steps, the depth schedule how deep the tree is; every `updatesPerEvaluation` steps (first
     after step 1) the validation strategies run, results are logged and a 'Current' checkpoint is written; further
     checkpoints by `saveFreq` / `epochSaveFreq` (schedules.ModelSaveFrequencyTracker).  `mainSavePath` (extra keyword) roots
-    the checkpoints.  Returns the log rows."""
+    the checkpoints.  Returns the log rows.
+
+    Extra keywords: `useGraphs=True` runs every micro-step as graphs.GraphedTrainStep replays (one captured step per distinct
+    sampling config / depth, built on first use without training the model) - the path bench.py measures; `ampDtype`
+    (torch.bfloat16 or None) is the autocast dtype of those steps."""
     from . import checkpoint, schedules
     sched = genDiscUpdateSchedule if genDiscUpdateSchedule is not None else schedules.AlwaysUpdateSchedule()
     tracker = schedules.ModelSaveFrequencyTracker(kwargs.pop('saveFreq', None), len(trainDataset), enabled=saveModel,
                                                   epochSaveFrequency=kwargs.pop('epochSaveFreq', None))
     save_root, sink = kwargs.pop('mainSavePath', ''), kwargs.pop('logSink', print)
+    use_graphs, amp_dtype, graphed = kwargs.pop('useGraphs', False), kwargs.pop('ampDtype', None), {}
+
+    def conf_key(conf):
+        return (conf.numSampleSequences, conf.includeAllMultiStepSamplesForDisc,
+                tuple((r.numAlterations, getattr(r.samplingStrategy, "name", r.samplingStrategy), repr(sorted((r.samplingParams or {}).items())),
+                       r.continueFromRandom) for r in conf.rules))
+
+    def join_graphs():
+        for gs in graphed.values():
+            gs.join()
     depthSchedule = getattr(trainingConf, 'depthSchedule', None)
     rlConf = getattr(trainingConf, 'reinforcementLearningConfig', None)
 
@@ -334,12 +352,25 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
             if depthSchedule is not None:
                 depthSchedule.updateSchedule(epochCounter, i, stepCounter)
                 conf = depthSchedule.setSampleConfDepth(conf)
-            discLosses, genLosses = train_step(model, bIDs, conf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples, rlConf,
-                                               updateGen=updateGen, updateDisc=updateDisc, **kwargs)
+            if use_graphs:
+                key = conf_key(conf)
+                if key not in graphed:
+                    from .graphs import GraphedTrainStep
+                    join_graphs()
+                    graphed[key] = GraphedTrainStep(model, conf, generatorOptim, discriminatorOptim, bIDs, numUpdateSamples, rlConf, amp_dtype)
+                else:
+                    for k, gs in graphed.items():              # a deferred discriminator step of another captured config
+                        if k != key:
+                            gs.join()
+                discLosses, genLosses = graphed[key].step(bIDs, stepCounter, updateGen, updateDisc, sampleConf=conf)
+            else:
+                discLosses, genLosses = train_step(model, bIDs, conf, generatorOptim, discriminatorOptim, stepCounter, numUpdateSamples, rlConf,
+                                                   updateGen=updateGen, updateDisc=updateDisc, **kwargs)
             _appendToCollectedData(discData, discLosses)
             _appendToCollectedData(genData, genLosses)
             stepCounter += 1
             if stepCounter % updatesPerEvaluation == 1:             # == 1: an early first evaluation, as in the reference
+                join_graphs()
                 validationResult = validateModel(model, testData, samplingStrategies=validationSamplingConf, displayProgress=displayProgression)
                 if doLogData:
                     log.extend(logResults(validationResult, genData, discData, trainDataset, epochCounter, i, generatorOptim, discriminatorOptim,
@@ -349,8 +380,10 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
                     save('Current')
             due, name = tracker.shouldModelBeSaved(i, epochCounter)
             if saveModel and due:
+                join_graphs()
                 save(name)
         epochCounter += 1
+        join_graphs()
         if saveModel and tracker.epochSaveFrequency and tracker.shouldModelBeSavedAtThisEpoch(epochCounter):
             save("Epoch-{}".format(epochCounter))
     return log

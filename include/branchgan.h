@@ -335,6 +335,19 @@ int bg_rl_loss_bwd(const bg_rl_loss_shape* shape, const float* input_scores, con
                    const float* depth_mask, const float* g_losses,
                    float* d_label_logp, float* d_alt_logp, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * hipGraph hygiene for a captured train step.  No counterpart in the reference (it runs eagerly); these exist because
+ * on ROCm 7.2.0 a MEMSET node of an instantiated graph (a captured hipMemsetAsync) clears its destination on the first
+ * replay and fills it with garbage from the second on (sizes >= 16 B; benchmarks/probes/graph_anomalies.py), which breaks
+ * every captured ATen multi-block reduction (their arrival counters are cleared by such a call).
+ * `graph` is a hipGraph_t that has NOT been instantiated yet (host call, no stream).
+ * bg_graph_node_census: node counts by type (any output pointer may be NULL).
+ * bg_graph_replace_memset_nodes: replaces every memset node by a kernel node (a fill kernel of this library with the same
+ *   destination, value, element size, width, height, pitch) wired to the same predecessors and successors.
+ */
+int bg_graph_node_census(void* graph, int* n_nodes, int* n_kernel, int* n_memset, int* n_memcpy);
+int bg_graph_replace_memset_nodes(void* graph, int* n_replaced);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ def _run(rank, world, port, tmp, variant):
     b = 4 // world
     mine = data[:, rank * b:(rank + 1) * b]
     if graphed:
-        step = GraphedTrainStep(model, conf, g_opt, d_opt, mine[0], 9999, rl, None, warmup=3)     # 3 eager steps on batch 0
+        step = GraphedTrainStep(model, conf, g_opt, d_opt, mine[0], 9999, rl, None, warmup=3, restore_after_warmup=False)     # 3 eager steps on batch 0, kept
         assert step._defer_d == (world > 1)
         for i in range(2):
             step.step(mine[1 + i], 3 + i)

@@ -96,6 +96,34 @@ def test_update_schedule_freezes_the_generator():
     assert any(not torch.equal(v, before_d[k]) for k, v in model.discriminator.state_dict().items())
 
 
+def test_training_loop_on_graph_replays_matches_the_eager_loop():
+    """efficentTrainingLoop(useGraphs=True): every micro-step is a GraphedTrainStep replay (one captured step per depth, built on
+    first use without training the model), under the same update and depth schedules as the eager loop -> same parameters."""
+    from branchgan import configs, schedules, training
+
+    def run(use_graphs):
+        model, train_conf, _ = _setup()
+        g = torch.Generator().manual_seed(1)
+        train = [torch.randint(0, 2048, (4, 32), generator=g).cuda() for _ in range(6)]
+        g_opt = training.OptimizerWrapper(model.generator, training.make_optimizer(model.generator.parameters(), 'adam', 1e-4, betas=(0.5, 0.999)))
+        d_opt = training.OptimizerWrapper(model.discriminator, training.make_optimizer(model.discriminator.parameters(), 'adam', 1e-3))
+        train_conf.sparseIndex = torch.tensor([1, 5, 9, 13, 17, 21, 25, 29], device="cuda")
+        conf = types.SimpleNamespace(depthSchedule=configs.LinearUpdatesDepthSchedule(1, 1, 2, 3), reinforcementLearningConfig=None, saveOptimizers=False)
+        rows = []
+        training.efficentTrainingLoop(model, train, None, 1, g_opt, d_opt, train_conf, 9999, 100, {}, saveModel=False,
+                                      genDiscUpdateSchedule=schedules.GeneratorSlowStart(2), trainingConf=conf, logSink=rows.append,
+                                      useGraphs=use_graphs)
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}, rows
+
+    eager, rows_e = run(False)
+    graphed, rows_g = run(True)
+    for k in eager:
+        torch.testing.assert_close(graphed[k], eager[k], rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    le = [r["Generator-loss"] for r in rows_e if "Generator-loss" in r]
+    lg = [r["Generator-loss"] for r in rows_g if "Generator-loss" in r]
+    np.testing.assert_allclose(lg, le, rtol=1e-5)
+
+
 def test_token_stream_prefetch_to_gpu(tmp_path):
     """The pinned-buffer / side-stream staging hands out the same batches as the CPU stream, in order, over three epochs."""
     import json

@@ -109,3 +109,37 @@ def test_arena_adam_matches_torch_adam_through_the_wrapper():
         net.b.weight.mul_(2.0)
     fused.invalidate_weights()
     assert torch.equal(fused.lowp(net.b.weight, torch.bfloat16), net.b.weight.detach().to(torch.bfloat16))
+
+
+def test_resume_from_checkpoint_before_the_first_step(tmp_path):
+    """The reference's resume flow (SpawnedExperiment.py:27-34): build the model and the optimizer wrappers, load the start
+    weights and the optimizer state, THEN train.  ArenaAdam has no arenas at that point: the loaded moments and step count
+    are kept and copied in when the first step lays the arenas out.  A run resumed that way continues exactly like the
+    uninterrupted one."""
+    from branchgan import checkpoint, configs, gan, sampling, training
+
+    def build():
+        torch.manual_seed(0)
+        model = gan.GannSetup("gpt2-tiny", "gpt2-tiny", device="cuda").cuda()
+        g_opt = training.OptimizerWrapper(model.generator, training.make_optimizer(model.generator.parameters(), 'adam', 1e-3, betas=(0.5, 0.999)))
+        d_opt = training.OptimizerWrapper(model.discriminator, training.make_optimizer(model.discriminator.parameters(), 'adam', 1e-3))
+        return model, g_opt, d_opt
+
+    rules = [sampling.SamplingRule(1, sampling.SamplingTechniques.TOP_K, {}) for _ in range(2)]
+    conf = configs.SamplingConfig(rules, includeAllMultiStepSamplesForDisc=True, numSampleSequences=8, seed=3)
+    conf.sparseIndex = torch.tensor([1, 5, 9, 13, 17, 21, 25, 29], device="cuda")
+    data = torch.randint(0, 2048, (4, 4, 32), generator=torch.Generator().manual_seed(2)).cuda()
+    model, g_opt, d_opt = build()
+    for i in range(3):
+        training.train_step(model, data[i], conf, g_opt, d_opt, i, 9999, None)
+    checkpoint.saveGannSetup(model, "run", "Mid", d_opt, g_opt, mainSavePath=str(tmp_path), saveOptimizers=True)
+    training.train_step(model, data[3], conf, g_opt, d_opt, 3, 9999, None)
+    want = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    fresh, g2, d2 = build()
+    checkpoint.loadGannSetup(fresh, str(tmp_path / "run" / "Mid"), d2, g2)          # no step has run: the arenas do not exist yet
+    assert g2.optimizer.param_arena is None and g2.optimizer._pending_state
+    training.train_step(fresh, data[3], conf, g2, d2, 3, 9999, None)
+    assert g2.optimizer.steps == 4 and d2.optimizer.steps == 4
+    for k, v in fresh.state_dict().items():
+        torch.testing.assert_close(v, want[k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
