@@ -1,0 +1,1 @@
+"""Import-compatibility package: the reference's `Models.Losses` import path over this build's `branchgan` package (a user of the reference switches nothing but sys.path)."""

@@ -64,6 +64,7 @@ SIGNATURES = {
     "bg_branch_attn_bwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                    ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_vp]),
+    "bg_branch_attn_weights": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
@@ -82,6 +83,9 @@ SIGNATURES = {
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
     "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),
+    "bg_dual_head_advantages": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_f32] * 3 + [c_i32] * 2 + [c_f32] * 2 + [c_vp] * 6 + [c_vp]),
+    "bg_reinforce_terms_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    "bg_reinforce_terms_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     "bg_graph_node_census": (c_i32, [c_vp] + [ctypes.POINTER(c_i32)] * 4),
     "bg_graph_replace_memset_nodes": (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     "bg_rl_loss_bwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp, c_vp, c_vp]),

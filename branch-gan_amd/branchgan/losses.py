@@ -72,6 +72,45 @@ def reinforceLosses(labelLogProbs, alterationLogProbs, discInputScores, discAlte
             'unweightedCombined': (inputLoss + alterationLoss) / (1 + N)}
 
 
+# ---- the reference's own function boundaries (the train step runs the fused kernels above) --------------------------------
+def dualHeadAdvantages(discInputScores, alterationScores, inputValueHeadPred, alterationValueHeadPred, advantageSectionWeights,
+                       inputIncorrectValueHeadsPolicy, alterationIncorrectValueHeadsPolicy, minZoneCLoss=0.1, epsilon=0.00001,
+                       min_denominator_value=1e-5):
+    """AdvantageCalculations.py:5-46, same arguments and return structure:
+    (inputAdvantages (B,1,S), alterationAdvantages (B,N,S), (zoneA, zoneB, zoneC (B,1+N,S), advantageCorrectMask (B,S),
+    inputCorrectMask (B,S))), all float32, no gradient.  One launch of bg_dual_head_advantages."""
+    w = advantageSectionWeights
+    ignore = lambda policy: IncorrectValueHeadsPolicy(int(getattr(policy, "value", policy))) == IncorrectValueHeadsPolicy.IGNORE_SAMPLE
+    adv, zA, zB, zC, ok, in_ok = ops.dual_head_advantages(discInputScores, alterationScores, inputValueHeadPred.squeeze(-1),
+                                                          alterationValueHeadPred.squeeze(-1), w.A, w.B, w.C,
+                                                          ignore(inputIncorrectValueHeadsPolicy), ignore(alterationIncorrectValueHeadsPolicy),
+                                                          epsilon, min_denominator_value)
+    return adv[:, :1], adv[:, 1:], (zA, zB, zC, ok, in_ok)
+
+
+def calculateMinimumProbLimit(advantages, policyProbs, negPushProbLimit=0.1):
+    """ReinforceLoss.py:11-18 (a mask; reinforceLoss applies it inside the kernel)."""
+    rewardMask = torch.greater_equal(advantages, 0).float()
+    inverted = 1 - rewardMask
+    return rewardMask + torch.where(policyProbs * inverted >= negPushProbLimit, inverted, rewardMask)
+
+
+def calculateAdvantageMask(advantages, policyProbs, powerWeight=0.05):
+    """ReinforceLoss.py:4-8 (unused by the reference's loss; kept for the import surface)."""
+    rewardMask = torch.greater_equal(advantages, 0).float()
+    return (policyProbs * (1 - rewardMask) + rewardMask) ** powerWeight
+
+
+def reinforceLoss(policyProbs, advantages, useNegativeEntropyMask, useMinProbLimit, negPushProbLimit=1e-8, eps=1e-6):
+    """ReinforceLoss.py:45-52: -log(clamp(p)) * advantages [* calculateMinimumProbLimit]; useNegativeEntropyMask is unused there too."""
+    return ops.reinforce_terms(policyProbs, advantages, None, useMinProbLimit, negPushProbLimit, eps)
+
+
+def mirroredNegativeReinforceLoss(policyProbs, advantages, maskZoneC):
+    """ReinforceLoss.py:28-42: the plain term outside zone C, -log(1 - p) * advantages inside."""
+    return ops.reinforce_terms(policyProbs, advantages, maskZoneC)
+
+
 def mleLossFromLabelLogProbs(labelLogProbs):
     """_mleLossFromLogits (GeneratorLosses.py:133-137): CE = -mean log p(label); labelLogProbs comes from bg_softmax_stats."""
     return -labelLogProbs.mean()

@@ -78,20 +78,29 @@ def _legacy_layer_past(layer_past, mask, K, device):
                            paths=[list(range(n_anc + 1))], n_query_nodes=1)
 
 
-def branch_attention_core(q, k, v, lp, scale):
-    """q, k, v (B,H,NQ*K,Dh) of the new tokens; lp = layer view of a BranchPast.  -> (B,H,NQ*K,Dh)."""
+def branch_attention_core(q, k, v, lp, scale, return_weights=False):
+    """q, k, v (B,H,NQ*K,Dh) of the new tokens; lp = layer view of a BranchPast.  -> (B,H,NQ*K,Dh), and with return_weights
+    the softmax weights the reference materialises ((B,H,K,C+1) for one query node, (B,H,NQ,K,W) for several), rebuilt by
+    bg_branch_attn_weights from the forward's log-sum-exp."""
     NQ = lp.n_query_nodes
     K = q.shape[2] // NQ
     q5, k5, v5 = q.unflatten(2, (NQ, K)), k.unflatten(2, (NQ, K)), v.unflatten(2, (NQ, K))
-    out, _ = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, [a[0] for a in lp.ancestors], [a[1] for a in lp.ancestors],
-                                  paths=lp.paths, scale=scale, own_k=k5, own_v=v5)
-    return out.flatten(2, 3)
+    anc_k = [a[0] for a in lp.ancestors]
+    out, lse = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, anc_k, [a[1] for a in lp.ancestors],
+                                    paths=lp.paths, scale=scale, own_k=k5, own_v=v5)
+    if not return_weights:
+        return out.flatten(2, 3)
+    w = ops.branch_attention_weights(q5, lp.text[0], lp.ctx_len, anc_k, lp.paths, scale, lse, own_k=k5).to(v.dtype)
+    return out.flatten(2, 3), (w[:, :, 0] if NQ == 1 else w)
 
 
-def dense_weights_from(q, k_self, k_ctx, mask, scale):
-    """Debug helper for output_attentions=True: the (B,H,K,C+1) weights the reference materialises."""
-    s = torch.cat((q @ k_ctx.transpose(-1, -2), (q * k_self).sum(-1, keepdim=True)), -1) * scale
-    return torch.softmax(s.masked_fill(~mask, float("-inf")), -1)
+def causal_attention_core(q, k, v, scale, return_weights=False):
+    """Root causal pass (+ its (B,H,T,S) weights on request)."""
+    out, lse = ops.causal_attention(q, k, v, scale=scale)
+    if not return_weights:
+        return out, None
+    ctx = ops.causal_ctx_len(q.shape[2], k.shape[2], q.device)
+    return out, ops.branch_attention_weights(q, k, ctx, [], [[]], scale, lse).to(v.dtype)
 
 
 def _check_no_attn_dropout(p):
@@ -151,12 +160,15 @@ class NeoXNonResidualAttention(nn.Module):
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
 
     def _nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
-                                  customCasualMask=None, dropoutRate=None):
-        """Reference signature (:183-184); dropoutRate is accepted and ignored there too."""
+                                  customCasualMask=None, dropoutRate=None, output_attentions=False):
+        """Reference signature (:183-184); dropoutRate is accepted and ignored there too.  The reference always returns the
+        (B,H,K,C+1) weights; here they are formed only under output_attentions=True, else None."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported on the fused path")
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
-        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor), None   # weights are never formed
+        if output_attentions:
+            return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, return_weights=True)
+        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor), None
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, head_mask=None, layer_past=None,
                 use_cache=False, output_attentions=False, isNonResidual=False, textualPast=None, customCasualMask=None):
@@ -169,16 +181,19 @@ class NeoXNonResidualAttention(nn.Module):
                                               self.rotary_ndims)
         present = (key, value) if use_cache else None
         scale = 1.0 / self.norm_factor
+        weights = None
         if isNonResidual:
             lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
-            attn_output = branch_attention_core(query, key, value, lp, scale)
+            attn_output = branch_attention_core(query, key, value, lp, scale, return_weights=output_attentions)
+            if output_attentions:
+                attn_output, weights = attn_output
         else:
-            attn_output, _ = ops.causal_attention(query, key, value, scale=scale)
+            attn_output, weights = causal_attention_core(query, key, value, scale, return_weights=output_attentions)
         attn_output = attn_output.permute(0, 2, 1, 3).reshape(B, T, self.hidden_size)
         attn_output = self.dense(attn_output)
         outputs = (attn_output, present)
         if output_attentions:
-            outputs += (None,)          # the fused kernel never forms the weights
+            outputs += (weights,)       # rebuilt from the forward's log-sum-exp on request; the hot path never forms them
         return outputs
 
 
@@ -441,12 +456,14 @@ class GPT2NonResidualAttention(nn.Module):
         return s / float(self.layer_idx + 1) if self.scale_attn_by_inverse_layer_idx else s
 
     def nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
-                                 customCasualMask=None, dropoutRate=None):
-        """Reference signature (:119-120)."""
+                                 customCasualMask=None, dropoutRate=None, output_attentions=False):
+        """Reference signature (:119-120); the weights only under output_attentions=True (else None)."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported on the fused path")
         _check_no_attn_dropout(dropoutRate if dropoutRate is not None else self.config.attn_pdrop)
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
+        if output_attentions:
+            return branch_attention_core(query, key, value, lp, self._scale(), return_weights=True)
         return branch_attention_core(query, key, value, lp, self._scale()), None
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None, encoder_hidden_states=None,
@@ -461,18 +478,21 @@ class GPT2NonResidualAttention(nn.Module):
         qkv = self.c_attn(hidden_states).view(B, T, 3, self.num_heads, self.head_dim)
         query, key, value = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]     # strided views, no copies
         present = (key, value) if use_cache else None
+        weights = None
         if nonResidualTextOnly:
             lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
-            attn_output = branch_attention_core(query, key, value, lp, self._scale())
+            attn_output = branch_attention_core(query, key, value, lp, self._scale(), return_weights=output_attentions)
+            if output_attentions:
+                attn_output, weights = attn_output
         else:
-            attn_output, _ = ops.causal_attention(query, key, value, scale=self._scale())
+            attn_output, weights = causal_attention_core(query, key, value, self._scale(), return_weights=output_attentions)
         attn_output = self.c_proj(attn_output.permute(0, 2, 1, 3).reshape(B, T, self.embed_dim))
         p = dropoutRate if dropoutRate is not None else self.config.resid_pdrop
         if p:
             attn_output = F.dropout(attn_output, p)          # always-on like the reference (:274-275, quirk 1)
         outputs = (attn_output, present)
         if output_attentions:
-            outputs += (None,)
+            outputs += (weights,)
         return outputs
 
 

@@ -342,9 +342,43 @@ def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=N
     path, path_len, max_path = path_tables(paths, q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
+    if own_k is not None and slots_k and NQ == 1 and any(t.stride() != own_k[:, :, 0].stride() for t in list(slots_k) + list(slots_v)):
+        # reference-form call: the ancestors are slices of one concatenated context (getFullPast), laid out differently from the
+        # step's own keys - one packed copy each (differentiable) gives every slot the same strides
+        slots_k, slots_v = [t.contiguous() for t in slots_k], [t.contiguous() for t in slots_v]
+        own_k, own_v = own_k.contiguous(), own_v.contiguous()
     out, lse = _BranchAttention.apply(q, k_text, v_text, ctx_len.contiguous(), path, path_len, max_path, float(scale),
                                       len(slots_k), own_k, own_v, *slots_k, *slots_v)
     return (out.squeeze(2), lse.squeeze(2)) if squeeze else (out, lse)
+
+
+def branch_attention_weights(q, k_text, ctx_len, slots_k, paths, scale, lse, own_k=None):
+    """The softmax weights of a branch_attention call, on request (bg_branch_attn_weights; no gradient).  Arguments as
+    branch_attention; lse is the one it returned.  -> fp32 (B,H,NQ,K,W), W = S + (max_path - 1) * K + 1, the reference's
+    column order [text | one K-column block per ancestor | self]."""
+    squeeze = q.dim() == 4
+    if squeeze:
+        q, lse = q.unsqueeze(2), lse.unsqueeze(2)
+        own_k = own_k.unsqueeze(2) if own_k is not None and own_k.dim() == 4 else own_k
+    q, k_text = _unit_last(q.detach()), _unit_last(k_text.detach())
+    B, H, NQ, K, Dh = q.shape
+    slots = [t.detach() for t in slots_k]
+    if own_k is not None:
+        own_k = _unit_last(own_k.detach())
+        slots = slots + [own_k[:, :, n] for n in range(NQ)]
+    if slots and any(t.stride() != slots[0].stride() or t.stride(-1) != 1 for t in slots):
+        slots = [t.contiguous() for t in slots]
+    if paths is None:
+        paths = [list(range(len(slots)))] * NQ
+    path, path_len, max_path = path_tables(paths, q.device)
+    W = k_text.shape[2] + (max(max_path - 1, 0) * K + 1 if max_path else 0)
+    weights = torch.empty((B, H, NQ, K, max(W, 1)), dtype=torch.float32, device=q.device)
+    sh = _attn_shape(q, k_text, slots, scale, max_path, q)
+    lse = lse.detach().contiguous().float()
+    C.check(C.lib().bg_branch_attn_weights(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), _ptr_array(slots), C.ptr(ctx_len.contiguous()),
+                                           C.ptr(path), C.ptr(path_len), C.ptr(lse), C.ptr(weights), weights.shape[-1], C.stream_ptr()),
+            "bg_branch_attn_weights")
+    return weights.squeeze(2) if squeeze else weights
 
 
 _arange_cache = {}
@@ -505,3 +539,62 @@ def rl_losses(label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, dep
     discriminator tensors carry no gradient.  -> fp32 [loss-RL-input, loss-RL-alterations]."""
     return _RlLosses.apply(label_lp, alt_lp, input_scores.detach(), alt_scores.detach(), in_head.detach(), alt_head.detach(),
                            depth_mask, wA, wB, wC, ignore_input, ignore_alt, probs_input)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The element-wise pieces of the generator loss under the reference's own function boundaries
+# ---------------------------------------------------------------------------------------------------
+def dual_head_advantages(input_scores, alt_scores, in_head, alt_head, wA, wB, wC, ignore_input, ignore_alt, epsilon=1e-5,
+                         min_denominator=1e-5):
+    """bg_dual_head_advantages (AdvantageCalculations.py:5-46).  input_scores (B,S), alt_scores (B,N,S), heads (B,S), fp32.
+    -> advantages (B,1+N,S), zoneA, zoneB, zoneC (B,1+N,S), heads_correct (B,S), input_correct (B,S); no gradient."""
+    C.require_cuda(input_scores, alt_scores, in_head, alt_head)
+    f = lambda t: t.detach().contiguous().float()
+    input_scores, alt_scores, in_head, alt_head = f(input_scores), f(alt_scores), f(in_head), f(alt_head)
+    B, N, S = alt_scores.shape
+    if input_scores.shape != (B, S) or in_head.shape != (B, S) or alt_head.shape != (B, S):
+        raise ValueError(f"dual_head_advantages: scores (B,S) / (B,N,S) and heads (B,S) expected, got {tuple(input_scores.shape)}, "
+                         f"{tuple(alt_scores.shape)}, {tuple(in_head.shape)}, {tuple(alt_head.shape)}")
+    dev = alt_scores.device
+    big = [torch.empty((B, 1 + N, S), dtype=torch.float32, device=dev) for _ in range(4)]
+    small = [torch.empty((B, S), dtype=torch.float32, device=dev) for _ in range(2)]
+    C.check(C.lib().bg_dual_head_advantages(C.ptr(input_scores), C.ptr(alt_scores), C.ptr(in_head), C.ptr(alt_head), B, N, S,
+                                            float(wA), float(wB), float(wC), int(bool(ignore_input)), int(bool(ignore_alt)),
+                                            float(epsilon), float(min_denominator), *[C.ptr(t) for t in big + small], C.stream_ptr()),
+            "bg_dual_head_advantages")
+    return (*big, *small)
+
+
+class _ReinforceTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, adv, mask_c, use_min_prob, neg_push, eps):
+        C.require_cuda(probs, adv, mask_c)
+        shape = torch.broadcast_shapes(probs.shape, adv.shape, *(() if mask_c is None else (mask_c.shape,)))
+        f = lambda t: t.detach().expand(shape).contiguous().float()
+        p, a = f(probs), f(adv)
+        m = None if mask_c is None else f(mask_c)
+        loss = torch.empty(shape, dtype=torch.float32, device=p.device)
+        C.check(C.lib().bg_reinforce_terms_fwd(C.ptr(p), C.ptr(a), C.ptr(m), p.numel(), int(bool(use_min_prob)), float(neg_push), float(eps),
+                                               C.ptr(loss), C.stream_ptr()), "bg_reinforce_terms_fwd")
+        ctx.save_for_backward(p, a, *(() if m is None else (m,)))
+        ctx.meta = (int(bool(use_min_prob)), float(neg_push), float(eps), probs.shape, m is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        use_min_prob, neg_push, eps, in_shape, has_mask = ctx.meta
+        p, a = ctx.saved_tensors[:2]
+        m = ctx.saved_tensors[2] if has_mask else None
+        g = g.contiguous().float()
+        d = torch.empty_like(p)
+        C.check(C.lib().bg_reinforce_terms_bwd(C.ptr(p), C.ptr(a), C.ptr(m), p.numel(), use_min_prob, neg_push, eps, C.ptr(g), C.ptr(d),
+                                               C.stream_ptr()), "bg_reinforce_terms_bwd")
+        if tuple(d.shape) != tuple(in_shape):
+            d = d.sum_to_size(in_shape)
+        return d, None, None, None, None, None
+
+
+def reinforce_terms(probs, advantages, mask_zone_c=None, use_min_prob_limit=False, neg_push_prob_limit=1e-8, eps=1e-6):
+    """bg_reinforce_terms_* (ReinforceLoss.py:21-52): per-element REINFORCE loss, mirrored inside zone C when a mask is given;
+    differentiable in probs."""
+    return _ReinforceTerms.apply(probs, advantages, mask_zone_c, use_min_prob_limit, neg_push_prob_limit, eps)

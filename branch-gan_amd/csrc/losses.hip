@@ -6,6 +6,8 @@
 // reductions does the whole loss; the figure of merit is latency, not bandwidth.  The reference's zero / 1e-5
 // padding of the K real branch columns up to S (GanSetup.py:151-167,202-207, MultiStepPrediction.py:59-65) is
 // evaluated arithmetically, never materialised.
+#include <algorithm>
+
 #include "common.h"
 
 namespace bg {
@@ -201,6 +203,68 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_loss_kernel(RlArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The element-wise pieces of the generator loss under the reference's own function boundaries (bg_dual_head_advantages,
+// bg_reinforce_terms_*): the fused rl_loss_kernel above is what the train step runs; these serve callers of
+// AdvantageCalculations.dualHeadAdvantages / ReinforceLoss.reinforceLoss / mirroredNegativeReinforceLoss.
+struct AdvArgs {
+  const float *in, *alt, *in_head, *alt_head;
+  int B, N, S;
+  float wA, wB, wC, eps, min_den;
+  int ignore_in, ignore_alt;
+  float *adv, *za, *zb, *zc, *ok, *in_ok;
+};
+
+__global__ __launch_bounds__(256) void dual_head_advantages_kernel(AdvArgs a) {
+  const int64_t total = (int64_t)a.B * (1 + a.N) * a.S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % a.S), r = (int)((i / a.S) % (1 + a.N)), b = (int)(i / ((int64_t)a.S * (1 + a.N)));
+    const float in_h = a.in_head[b * a.S + t], alt_h = a.alt_head[b * a.S + t];
+    // row 0: the input scores shifted left by one with a zero appended (AdvantageCalculations.py:14-17)
+    const float score = r == 0 ? (t + 1 < a.S ? a.in[b * a.S + t + 1] : 0.f) : a.alt[((int64_t)b * a.N + (r - 1)) * a.S + t];
+    const bool zone_a = score >= in_h, above = score >= alt_h;
+    const bool zone_c = !above, zone_b = zone_a != above;
+    const float den = fmaxf(fabsf(in_h - alt_h) + a.eps, a.min_den);
+    const float scaled = (score - alt_h) / den;
+    float adv = (zone_a ? 1.f : 0.f) * a.wA + scaled * (zone_b ? 1.f : 0.f) * a.wB + (zone_c ? 1.f : 0.f) * a.wC;
+    const float heads_ok = alt_h >= in_h ? 0.f : 1.f;
+    if (r == 0 ? a.ignore_in : a.ignore_alt) adv *= heads_ok;
+    a.adv[i] = adv;
+    if (a.za) a.za[i] = zone_a ? 1.f : 0.f;
+    if (a.zb) a.zb[i] = zone_b ? 1.f : 0.f;
+    if (a.zc) a.zc[i] = zone_c ? 1.f : 0.f;
+    if (r == 0) {
+      if (a.ok) a.ok[b * a.S + t] = heads_ok;
+      if (a.in_ok) a.in_ok[b * a.S + t] = a.in[b * a.S + t] >= alt_h ? 1.f : 0.f;   // un-shifted input score (:12)
+    }
+  }
+}
+
+// loss = (1 - m) * normal + m * mirrored, normal = -log(pc) * adv [* limit factor], mirrored = -log(1 - pc) * adv,
+// pc = clamp(p, eps, 1 - eps); m = mask_c (NULL: 0, the plain reinforceLoss).  d/dp is zero outside the clamp.
+template <bool BWD>
+__global__ __launch_bounds__(256) void reinforce_terms_kernel(const float* probs, const float* adv, const float* mask_c, int64_t n,
+                                                              int use_min_prob, float neg_push, float eps, const float* g,
+                                                              float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float p = probs[i], ad = adv[i], m = mask_c ? mask_c[i] : 0.f;
+    const float pc = fminf(fmaxf(p, eps), 1.f - eps);
+    const bool pass = (p >= eps) && (p <= 1.f - eps);
+    float factor = 1.f;
+    if (use_min_prob) {            // calculateMinimumProbLimit (ReinforceLoss.py:11-18): rewardMask + negRewardMask
+      const float reward = ad >= 0.f ? 1.f : 0.f;
+      const float neg_p = pc * (1.f - reward);
+      factor = reward + (neg_p >= neg_push ? 1.f - reward : reward);
+    }
+    if constexpr (BWD) {
+      const float d = (1.f - m) * (-ad / pc) * factor + m * (ad / (1.f - pc));
+      out[i] = pass ? g[i] * d : 0.f;
+    } else {
+      out[i] = (1.f - m) * (-logf(pc) * ad) * factor + m * (-logf(1.f - pc) * ad);
+    }
+  }
+}
+
 static int check_disc(const bg_disc_loss_shape* s, const char* who) {
   BG_REQUIRE(s, "%s: null shape", who);
   BG_REQUIRE(s->B > 0 && s->S > 1 && s->N > 0 && s->K > 0 && s->K <= s->S, "%s: B=%d S=%d N=%d K=%d", who, s->B, s->S, s->N, s->K);
@@ -284,4 +348,43 @@ extern "C" int bg_rl_loss_bwd(const bg_rl_loss_shape* shape, const float* input_
   hipLaunchKernelGGL(rl_loss_kernel<true>, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
   BG_CHECK_LAUNCH("bg_rl_loss_bwd");
   return BG_OK;
+}
+
+extern "C" int bg_dual_head_advantages(const float* input_scores, const float* alt_scores, const float* in_head, const float* alt_head,
+                                       int B, int N, int S, float wA, float wB, float wC, int ignore_input, int ignore_alt,
+                                       float epsilon, float min_denominator, float* advantages, float* zone_a, float* zone_b,
+                                       float* zone_c, float* heads_correct, float* input_correct, void* stream) {
+  BG_REQUIRE(input_scores && alt_scores && in_head && alt_head && advantages, "bg_dual_head_advantages: null pointer");
+  BG_REQUIRE(B > 0 && N > 0 && S > 0 && (int64_t)B * (1 + N) * S < (1ll << 31), "bg_dual_head_advantages: B=%d N=%d S=%d", B, N, S);
+  AdvArgs a{input_scores, alt_scores, in_head, alt_head, B, N, S, wA, wB, wC, epsilon, min_denominator, ignore_input, ignore_alt,
+            advantages, zone_a, zone_b, zone_c, heads_correct, input_correct};
+  const int64_t total = (int64_t)B * (1 + N) * S;
+  hipLaunchKernelGGL(dual_head_advantages_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, a);
+  BG_CHECK_LAUNCH("bg_dual_head_advantages");
+  return BG_OK;
+}
+
+static int reinforce_terms(const char* who, bool bwd, const float* probs, const float* adv, const float* mask_c, int64_t n,
+                           int use_min_prob, float neg_push, float eps, const float* g, float* out, void* stream) {
+  BG_REQUIRE(probs && adv && out && (!bwd || g), "%s: null pointer", who);
+  BG_REQUIRE(n > 0 && n < (1ll << 40), "%s: n=%lld", who, (long long)n);
+  BG_REQUIRE(eps > 0.f && eps < 0.5f, "%s: eps=%g", who, eps);
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(n, 256), 2048));
+  if (bwd) hipLaunchKernelGGL(reinforce_terms_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, probs, adv, mask_c, n, use_min_prob, neg_push, eps, g, out);
+  else hipLaunchKernelGGL(reinforce_terms_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, probs, adv, mask_c, n, use_min_prob, neg_push, eps, g, out);
+  BG_CHECK_LAUNCH(who);
+  return BG_OK;
+}
+
+extern "C" int bg_reinforce_terms_fwd(const float* probs, const float* advantages, const float* mask_zone_c, int64_t n,
+                                      int use_min_prob_limit, float neg_push_prob_limit, float eps, float* loss, void* stream) {
+  return reinforce_terms("bg_reinforce_terms_fwd", false, probs, advantages, mask_zone_c, n, use_min_prob_limit, neg_push_prob_limit, eps,
+                         nullptr, loss, stream);
+}
+
+extern "C" int bg_reinforce_terms_bwd(const float* probs, const float* advantages, const float* mask_zone_c, int64_t n,
+                                      int use_min_prob_limit, float neg_push_prob_limit, float eps, const float* g_loss,
+                                      float* d_probs, void* stream) {
+  return reinforce_terms("bg_reinforce_terms_bwd", true, probs, advantages, mask_zone_c, n, use_min_prob_limit, neg_push_prob_limit, eps,
+                         g_loss, d_probs, stream);
 }

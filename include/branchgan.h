@@ -188,6 +188,17 @@ int bg_branch_attn_bwd(const bg_attn_shape* shape,
                        void* const* dk_slots, void* const* dv_slots,             /* host arrays */
                        float* delta /* fp32 scratch [b][h][n][k] */, void* stream);
 
+/* The softmax weights on request (the reference returns them from _nonResidualTextAttention and its modules hand them out
+ * under output_attentions=True: NeoXNonResidualAttention.py:224-232, NonResidualAttention.py:160-172).  The fused kernels never
+ * form them; this rebuilds them from q, the keys and the forward's lse:
+ *   weights fp32 [b][h][n][k][W], W >= S_text + (max_path - 1) * K + 1, in the reference's column order
+ *   [text 0..S_text-1 | path entry 0: K columns, only column k set | ... | last column: the node's last path entry (itself)];
+ *   invisible keys get weight 0.  A diagnostic path (one workgroup per query row), not a tuned kernel.
+ */
+int bg_branch_attn_weights(const bg_attn_shape* shape, const void* q, const void* k_text, const void* const* k_slots /* host array */,
+                           const int32_t* ctx_len, const int32_t* path, const int32_t* path_len, const float* lse,
+                           float* weights, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeoX prologue: split the fused QKV projection, move heads forward and apply partial rotary.
  * Replaces NeoXNonResidualAttention.py:94-115 (view/permute/slices) and :425-432 (apply_rotary_pos_emb
@@ -334,6 +345,32 @@ int bg_rl_loss_bwd(const bg_rl_loss_shape* shape, const float* input_scores, con
                    const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
                    const float* depth_mask, const float* g_losses,
                    float* d_label_logp, float* d_alt_logp, void* stream);
+
+/* The element-wise pieces of the generator loss under the reference's own function boundaries (the train step itself runs the
+ * fused bg_rl_loss_* above).
+ * bg_dual_head_advantages = Models/Losses/AdvantageCalculations.py:5-46 (dualHeadAdvantages):
+ *   input_scores fp32 [B][S]; alt_scores fp32 [B][N][S]; in_head, alt_head fp32 [B][S] (the text value heads, squeezed);
+ *   scores[b][0][t] = input_scores[b][t+1] (0 at t = S-1), scores[b][1+n][t] = alt_scores[b][n][t];
+ *   zone A: score >= in_head, zone C: score < alt_head, zone B: between (xor); zone B is scaled by
+ *   (score - alt_head) / max(|in_head - alt_head| + epsilon, min_denominator);
+ *   advantages fp32 [B][1+N][S] = A*wA + scaled*B*wB + C*wC, zeroed where alt_head >= in_head for row 0 (ignore_input) /
+ *   rows 1.. (ignore_alt): IncorrectValueHeadsPolicy.IGNORE_SAMPLE.
+ *   Optional outputs (NULL: skipped): zone_a/b/c fp32 [B][1+N][S]; heads_correct fp32 [B][S] = !(alt_head >= in_head);
+ *   input_correct fp32 [B][S] = input_scores >= alt_head.
+ * bg_reinforce_terms_* = Models/Losses/ReinforceLoss.py:21-52: per element, with pc = clamp(p, eps, 1 - eps),
+ *   loss = (1 - m) * (-log(pc) * adv * f) + m * (-log(1 - pc) * adv);  m = mask_zone_c (NULL: 0 = reinforceLoss, else
+ *   mirroredNegativeReinforceLoss);  f = calculateMinimumProbLimit's factor when use_min_prob_limit, else 1.
+ *   backward: d_probs = g_loss * dloss/dp, zero where p lies outside [eps, 1 - eps] (the clamp's gradient).
+ */
+int bg_dual_head_advantages(const float* input_scores, const float* alt_scores, const float* in_head, const float* alt_head,
+                            int B, int N, int S, float wA, float wB, float wC, int ignore_input, int ignore_alt,
+                            float epsilon, float min_denominator, float* advantages, float* zone_a, float* zone_b,
+                            float* zone_c, float* heads_correct, float* input_correct, void* stream);
+int bg_reinforce_terms_fwd(const float* probs, const float* advantages, const float* mask_zone_c, int64_t n,
+                           int use_min_prob_limit, float neg_push_prob_limit, float eps, float* loss, void* stream);
+int bg_reinforce_terms_bwd(const float* probs, const float* advantages, const float* mask_zone_c, int64_t n,
+                           int use_min_prob_limit, float neg_push_prob_limit, float eps, const float* g_loss,
+                           float* d_probs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * hipGraph hygiene for a captured train step.  No counterpart in the reference (it runs eagerly); these exist because

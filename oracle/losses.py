@@ -77,6 +77,31 @@ def dual_head_advantages(input_scores, alt_scores, in_head, alt_head, wA, wB, wC
     return in_adv, alt_adv, zone_c.float()
 
 
+def dual_head_advantages_full(input_scores, alt_scores, in_head, alt_head, wA, wB, wC, in_policy, alt_policy, epsilon=1e-5, min_den=1e-5):
+    """dualHeadAdvantages with its whole return structure (AdvantageCalculations.py:44-46): the advantages plus
+    (zoneA, zoneB, zoneC, advantageCorrectMask, inputCorrectMask)."""
+    ih, ah = in_head.detach().squeeze(-1), alt_head.detach().squeeze(-1)
+    in_adv, alt_adv, zone_c = dual_head_advantages(input_scores, alt_scores, in_head, alt_head, wA, wB, wC, in_policy, alt_policy,
+                                                   epsilon, min_den)
+    shifted = torch.cat((input_scores[:, 1:], torch.zeros(input_scores.shape[0], 1)), dim=1)
+    scores = torch.cat((shifted.unsqueeze(1), alt_scores), dim=1)
+    zone_a = torch.greater_equal(scores, ih.unsqueeze(1))
+    zone_b = torch.logical_xor(zone_a, torch.greater_equal(scores, ah.unsqueeze(1)))
+    heads_ok = 1 - torch.greater_equal(ah, ih).int()
+    return in_adv, alt_adv, (zone_a.float(), zone_b.float(), zone_c, heads_ok.float(), torch.greater_equal(input_scores, ah).float())
+
+
+def reinforce_loss(policy_probs, advantages, use_min_prob_limit=False, neg_push_prob_limit=1e-8, eps=1e-6):
+    """reinforceLoss (ReinforceLoss.py:45-52) with calculateMinimumProbLimit (:11-18)."""
+    p = torch.clamp(policy_probs, eps, 1 - eps)
+    loss = -torch.log(p) * advantages
+    if use_min_prob_limit:
+        reward = torch.greater_equal(advantages, 0).float()
+        inverted = 1 - reward
+        loss = loss * (reward + torch.where(p * inverted >= neg_push_prob_limit, inverted, reward))
+    return loss
+
+
 def mirrored_negative_reinforce(policy_probs, advantages, zone_c, eps=1e-6):
     """mirroredNegativeReinforceLoss (ReinforceLoss.py:21-52): -log p·adv outside zone C, -log(1-p)·adv inside."""
     p = torch.clamp(policy_probs, eps, 1 - eps)

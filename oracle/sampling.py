@@ -16,6 +16,15 @@ def exponential_noise(shape, generator=None, epsilon=1e-14):
     return -torch.log(torch.rand(tuple(shape), generator=generator) + epsilon)
 
 
+def rolled_noise(noise, splits, counter):
+    """SampleBuffer.SamplingBuffer.getShapeRandBuffers (SampleBuffer.py:31-43): the stored noise with every non-batch dim i + 1
+    cut at splits[i][counter] and its two pieces swapped."""
+    for i in range(noise.dim() - 1):
+        cut = int(splits[i][counter])
+        noise = torch.cat((noise.narrow(i + 1, cut, noise.shape[i + 1] - cut), noise.narrow(i + 1, 0, cut)), dim=i + 1)
+    return noise
+
+
 def apply_temperature(probs, temperature):
     """SamplingStrategies.py:77-99: exp(log p / T), renormalised over the vocabulary."""
     if temperature == 0:

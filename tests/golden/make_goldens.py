@@ -533,8 +533,86 @@ def g9_text_metrics():
     print("wrote", path)
 
 
+def g10_boundary():
+    """Round 2: the rest of the drop-in boundary - default-mask branch attention at head sizes the HIP kernel takes (A3), the
+    generator-loss pieces under the reference's own function names, the noise buffer's roll-by-split, and the techniques
+    that draw from torch's global CPU generator (reproducible under a fixed seed)."""
+    import types
+    from BranchPredictions import SampleBuffer
+    from Models.Losses import AdvantageCalculations as AC, ReinforceLoss as RL
+    out = {}
+    B = 2
+    torch.manual_seed(1001)
+    for fam in ("neox", "gpt2"):
+        for Dh, H, Q, Kl in ((32, 2, 16, 40), (64, 1, 5, 9), (32, 1, 7, 7)):
+            if fam == "neox":
+                fn = NeoXNonResidualAttention(tiny_cfg("neox", hidden=H * Dh, heads=H))._nonResidualTextAttention
+            else:
+                fn = GPT2NonResidualAttention(tiny_cfg("gpt2", hidden=H * Dh, heads=H), layer_idx=0).nonResidualTextAttention
+            q, k, v = [torch.randn(B, H, Q, Dh, requires_grad=True) for _ in range(3)]
+            kc, vc = [torch.randn(B, H, Kl, Dh, requires_grad=True) for _ in range(2)]
+            o, w = fn(q, k, v, kc, vc)
+            go = torch.randn_like(o)
+            grads = torch.autograd.grad(o, [q, k, v, kc, vc], go)
+            for nm, t in zip(["q", "k", "v", "kctx", "vctx", "out", "weights", "gout", "dq", "dk", "dv", "dkctx", "dvctx"],
+                             [q, k, v, kc, vc, o, w, go, *grads]):
+                out[f"default_{fam}_{Dh}_{Q}_{Kl}_{nm}"] = t
+    # --- AdvantageCalculations.dualHeadAdvantages / ReinforceLoss.* ---
+    g = torch.Generator().manual_seed(1002)
+    Bn, N, S = 3, 4, 11
+    in_scores, alt_scores = torch.rand(Bn, S, generator=g), torch.rand(Bn, N, S, generator=g)
+    in_head, alt_head = torch.rand(Bn, S, 1, generator=g), torch.rand(Bn, S, 1, generator=g)
+    alt_head[0, 3] = in_head[0, 3]                       # a tie between the two heads (denominator clamp, >= comparisons)
+    alt_scores[1, 2, 5] = in_head[1, 5, 0]               # a score exactly on a zone boundary
+    w = types.SimpleNamespace(A=1.0, B=0.7, C=1.5)
+    P = RLM.IncorrectValueHeadsPolicy
+    for tag, pi, pa in (("ii", P.IGNORE_SAMPLE, P.IGNORE_SAMPLE), ("ni", P.DO_NOTHING, P.IGNORE_SAMPLE), ("nn", P.DO_NOTHING, P.DO_NOTHING)):
+        ia, aa, (zA, zB, zC, corr, incorr) = AC.dualHeadAdvantages(in_scores, alt_scores, in_head, alt_head, w, pi, pa)
+        for nm, t in zip(["in_adv", "alt_adv", "zoneA", "zoneB", "zoneC", "adv_correct", "input_correct"], [ia, aa, zA, zB, zC, corr, incorr]):
+            out[f"adv_{tag}_{nm}"] = t
+    for nm, t in zip(["in_scores", "alt_scores", "in_head", "alt_head"], [in_scores, alt_scores, in_head, alt_head]):
+        out["adv_" + nm] = t
+    out["adv_weights"] = np.asarray([w.A, w.B, w.C], dtype=np.float32)
+    probs = torch.rand(Bn, N, S, generator=g)
+    probs[0, 0, :4] = torch.tensor([0.0, 1.0, 1e-7, 1 - 1e-8])      # outside the clamp: zero gradient
+    probs.requires_grad_(True)
+    adv = torch.randn(Bn, N, S, generator=g)
+    maskC = (torch.rand(Bn, N, S, generator=g) > 0.5).float()
+    gl = torch.randn(Bn, N, S, generator=g)
+    for tag, fn in (("mirrored", lambda: RL.mirroredNegativeReinforceLoss(probs, adv, maskC)),
+                    ("plain", lambda: RL.reinforceLoss(probs, adv, False, False)),
+                    ("minprob", lambda: RL.reinforceLoss(probs, adv, False, True, negPushProbLimit=0.3))):
+        loss = fn()
+        out[f"rl_{tag}_loss"] = loss
+        out[f"rl_{tag}_dprobs"] = torch.autograd.grad(loss, probs, gl)[0]
+    for nm, t in zip(["probs", "adv", "maskC", "gloss"], [probs, adv, maskC, gl]):
+        out["rl_" + nm] = t
+    # --- SampleBuffer.SamplingBuffer: one noise tensor per shape, rolled by pre-drawn split points ---
+    np.random.seed(5)
+    torch.manual_seed(5)
+    buf = SampleBuffer.SamplingBuffer('cpu', numShuffleSplits=4)
+    shape = (2, 5, 13)
+    rolled = [buf.rand(shape).clone() for _ in range(6)]          # wraps around after 4 calls
+    noise, splits, _ = buf.shapeRandBuffers[shape]
+    out["buf_noise"], out["buf_splits"], out["buf_rolled"] = noise, np.asarray(splits, dtype=np.int64), torch.stack(rolled)
+    # --- techniques on torch's global CPU generator ---
+    probs2 = torch.softmax(3 * torch.randn(2, 6, 97, generator=g), -1)
+    ids2 = torch.randint(0, 97, (2, 6), generator=g)
+    out["rand_probs"], out["rand_ids"] = probs2, ids2
+    torch.manual_seed(77)
+    out["rand_RANDOM"] = SS.sampleFromGeneratorDistribution(probs2, 5, ids2, T.RANDOM)[0]
+    torch.manual_seed(78)
+    out["rand_EPSILON_GREEDY"] = SS.sampleFromGeneratorDistribution(probs2, 6, ids2, T.EPSILON_GREEDY, numRandomSamples=2)[0]
+    torch.manual_seed(79)
+    out["rand_EPSILON_GREEDY_final"] = SS.sampleFromGeneratorDistribution(probs2, 6, ids2, T.EPSILON_GREEDY, blockSamplingOfLabels=False,
+                                                                          includeFinalTimeStep=True, numRandomSamples=4)[0]
+    save("g10_boundary", **out)
+
+
 def main():
     torch.set_num_threads(1)  # fixed reduction order for reproducible fixtures
+    if sys.argv[1:] == ["g10"]:
+        return g10_boundary()
     if sys.argv[1:] == ["g9"]:
         return g9_text_metrics()
     if sys.argv[1:] == ["g8"]:
@@ -550,6 +628,7 @@ def main():
     g1_attention()
     g2_sampling()
     g4_losses()
+    g10_boundary()
     TK, NR = T.TOP_K.value, T.SAMPLE_NO_REPLACEMENT.value
     g3_g5("neox", "neox_chain4", [(1, TK, {})] * 4, 11, [1, 3, 6, 8, 10])
     g3_g5("neox", "neox_tree211", [(2, TK, {}), (1, NR, {}), (1, TK, {})], 12, [0, 2, 5, 9])
