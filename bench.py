@@ -5,6 +5,13 @@ JSON line on rank 0.  For N > 1 launch with torch.distributed.run (one rank per 
 
 Workload at N = 1 = BASELINE.json configs[1]: GPT-2 small generator and discriminator, seq 256, 32 branch points, depth 4
 (4 x TOP_K rules, 1 alteration each, like ConfigInstances/PileTraining.py:59-71), per-GPU batch 8.
+Other workloads (parity-test cases, not the driver's line): --workload c1 | c3 | c4 (train steps of BASELINE configs[0], [2], [3]),
+--workload c5 (BASELINE configs[4]: the branch-sampling sweep at 8192 x 50304).
+
+`roofline` = the dominant hand-written hot-path entry point, bg_branch_attn_bwd: ONE eager step records every attention launch
+it makes (ops.ATTN_RECORD: same tensors, shapes, strides), the recorded launches are captured into a HIP graph and replayed,
+timed with HIP events on the stream they run on.  bg_branch_attn_fwd (same method) and bg_adam_step (events around the launches
+of the timed steps) sit beside it.
 """
 import argparse
 import json
@@ -28,9 +35,14 @@ WORKLOADS = {
                name="Pythia-70M G+D, seq 128, 16 branches, depth 2, batch 4 (BASELINE configs[0])"),
     "c3": dict(gen="pythia-410m", disc="pythia-14m", S=128, K=32, D=8, B=8,
                name="Pythia-410M G / Pythia-14m D PileTraining config, seq 128, 32 branches, depth 8, batch 8/GPU (BASELINE configs[2])"),
+    "c4": dict(gen="pythia-1b", disc="pythia-410m", S=512, K=64, D=8, B=4,
+               name="Pythia-1B G / Pythia-410M D, seq 512, 64 branches, depth 8, batch 4/GPU (BASELINE configs[3], attention-bound stress)"),
+    "c5": dict(rows=8192, V=50304,
+               name="branch sampling sweep, 64 x 128 rows over a 50304 vocabulary: TOP_K n 1/4/16, TOP_P p 0.5/0.9, SAMPLE_NO_REPLACEMENT n 1/4 (BASELINE configs[4])"),
 }
 WORKLOADS["tiny"] = dict(gen="gpt2-tiny", disc="gpt2-tiny", S=64, K=8, D=3, B=4, name="rehearsal only: 2-layer 128-wide GPT-2 pair")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
 def zipf_ids(n, S, V, seed):
@@ -56,98 +68,98 @@ def build(workload, device, seed=0):
     return model, conf, rl, g_opt, d_opt
 
 
-def attention_forward_roofline(wl, device, dtype, reps=5):
-    """Roofline of the dominant hand-written kernel, branch_attn_fwd_kernel (the largest share of GPU time among this
-    library's kernels in a step, see profiles/).  One train step launches it with three shape classes per layer - root
-    causal pass, generator branch step at depth d (ancestor slots), tree pass over N nodes (generator gradient pass,
-    discriminator) - so the replay below issues EXACTLY one step's mix (same counts, shapes, strides, dtype: slices of a
-    packed QKV buffer like the fused block path) captured in a HIP graph, and times `reps` replays with HIP events on the
-    stream they are launched on.  Algorithmic bytes / FLOPs per launch follow SURVEY.md §8(d):
-      bytes = visible K/V read once (max ctx_len text rows + every slot's K rows) + Q read + O write;
-      flops = 4 * Dh * (visible query-key pairs)."""
-    from branchgan import configs, fused, ops
-    S, K, D, B = wl["S"], wl["K"], wl["D"], wl["B"]
-    e = 2 if dtype == torch.bfloat16 else 4
-    sparse = np.sort(np.random.RandomState(1234).choice(S - 1, K, replace=False))
-    ctx = torch.tensor(sparse + 1, dtype=torch.int32, device=device)
-    ctx_sum, ctx_max = int(ctx.sum()), int(ctx.max())
-    calls, tot_bytes, tot_flops = [], 0.0, 0.0
+def _pmc_traffic(name, expect_launches):
+    """HBM bytes per launch from the rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs over benchmarks/attn_mix.py or
+    benchmarks/sampling_mix.py, gfx950 corrections applied; a profiler cannot run inside this process).  Only used when the record
+    was taken on the same launch mix."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path))
+    if expect_launches is not None and rec.get("launches_per_step") not in (None, expect_launches):
+        return None, None
+    return rec.get("traffic_bytes_per_launch"), f"profiles/{name}"
 
-    def packed(T, H, Dh):
-        return torch.randn(B, T, 3, H, Dh, device=device).to(dtype)
 
-    def add(fn, nbytes, flops, count):
-        nonlocal tot_bytes, tot_flops
-        calls.extend([fn] * count)
-        tot_bytes += nbytes * count
-        tot_flops += flops * count
-
-    for name, has_branch_steps, n_tree in ((wl["gen"], True, D - 1), (wl["disc"], False, D)):
-        cfg = configs.LMConfig.from_any(name)
-        H, Dh, L = cfg.num_attention_heads, cfg.head_dim, cfg.num_hidden_layers
-        scale = 1.0 / Dh ** 0.5
-        root = packed(S, H, Dh)
-        att_r = torch.empty(B, S, H, Dh, device=device, dtype=dtype)
-        lse_r = torch.empty(B, H, 1, S, device=device)
-        kt, vt = root[:, :, 1].permute(0, 2, 1, 3), root[:, :, 2].permute(0, 2, 1, 3)
-        hf = fused._heads_first
-        add(lambda root=root, att_r=att_r, lse_r=lse_r, kt=kt, vt=vt, scale=scale:
-            fused._attn_fwd_call(hf(root[:, :, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, device), [[]], scale, hf(att_r, 1, S), lse_r),
-            4 * B * H * S * Dh * e, 4 * Dh * H * B * S * (S + 1) // 2, L)
-        steps = []
-        if has_branch_steps:                       # sampling passes: node at depth d sees d - 1 ancestor slots + itself
-            nodes = [packed(K, H, Dh) for _ in range(D - 1)]
-            for d in range(1, D):
-                steps.append((nodes[d - 1], [n[:, :, 1].permute(0, 2, 1, 3) for n in nodes[:d]], [n[:, :, 2].permute(0, 2, 1, 3) for n in nodes[:d]],
-                              [list(range(d))], 1))
-        tree = packed(n_tree * K, H, Dh)           # one pass over n_tree chain nodes
-        tk, tv = tree[:, :, 1].permute(0, 2, 1, 3), tree[:, :, 2].permute(0, 2, 1, 3)
-        steps.append((tree, [tk[:, :, n * K:(n + 1) * K] for n in range(n_tree)], [tv[:, :, n * K:(n + 1) * K] for n in range(n_tree)],
-                      [list(range(n + 1)) for n in range(n_tree)], n_tree))
-        for qkv, sk, sv, paths, NQ in steps:
-            att = torch.empty(B, NQ * K, H, Dh, device=device, dtype=dtype)
-            lse = torch.empty(B, H, NQ, K, device=device)
-            pairs = NQ * ctx_sum + K * sum(len(p) for p in paths)
-            add(lambda qkv=qkv, sk=sk, sv=sv, paths=paths, NQ=NQ, att=att, lse=lse, kt=kt, vt=vt, scale=scale:
-                fused._attn_fwd_call(hf(qkv[:, :, 0], NQ, K), kt, vt, sk, sv, ctx, paths, scale, hf(att, NQ, K), lse),
-                (2 * B * H * Dh * (ctx_max + len(sk) * K) + 2 * B * H * NQ * K * Dh) * e, 4 * Dh * H * B * pairs, L)
-    side = torch.cuda.Stream(device=device)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
+def _time_graph(calls, stream, reps):
+    """Captures the launch closures into one HIP graph on `stream` and returns the mean ms per launch over `reps` replays,
+    timed with HIP events recorded on that stream."""
+    with torch.cuda.stream(stream):
         for fn in calls:
             fn()
-    side.synchronize()
+    stream.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
+    with torch.cuda.graph(graph, stream=stream):
         for fn in calls:
             fn()
-    graph.replay()
-    torch.cuda.synchronize()
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(reps):
+    with torch.cuda.stream(stream):
         graph.replay()
-    t1.record()
-    torch.cuda.synchronize()
+        stream.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(reps):
+            graph.replay()
+        t1.record()
+        stream.synchronize()
+    return t0.elapsed_time(t1) / (reps * len(calls))
+
+
+def record_attention_launches(eager_step, index):
+    """Runs ONE eager train step with ops.ATTN_RECORD on: every bg_branch_attn_fwd / _bwd launch of the step, with the tensors it
+    ran on kept alive."""
+    from branchgan import ops
+    ops.ATTN_RECORD = []
+    try:
+        eager_step(index)
+        torch.cuda.synchronize()
+    finally:
+        rec, ops.ATTN_RECORD = ops.ATTN_RECORD, None
+    return rec
+
+
+def _launch_class(sh):
+    if sh.n_slots == 0:
+        return "root causal"
+    return "branch step" if sh.NQ == 1 else "tree pass"
+
+
+def attention_roofline(rec, kind, dtype_name, device, workload_key, reps=5):
+    """Roofline of bg_branch_attn_fwd / bg_branch_attn_bwd on one step's real launch mix (see the module docstring).
+    Algorithmic bytes / FLOPs per launch: ops.attn_launch_work.  For the backward a launch is the entry point's
+    kernels together (dq, dkv, slots)."""
+    from branchgan import ops
+    calls = [r for r in rec if r[0] == kind]
+    if not calls:
+        return None
+    work = [ops.attn_launch_work(r[2], r[3], r[4], kind, r[5][2]) for r in calls]
+    stream = torch.cuda.Stream(device=device)
+    stream.wait_stream(torch.cuda.current_stream())
     n = len(calls)
-    avg_ms = t0.elapsed_time(t1) / (reps * n)
-    # HBM traffic per launch from the PMC passes over this same launch mix (benchmarks/attn_mix.py under rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections applied): collected offline, a profiler cannot run in here
-    traffic, pmc = None, os.path.join(ROOT, "profiles", "r1_f_pmc_attn_fwd.json")
-    if wl.get("name") == WORKLOADS["c2"]["name"] and wl["B"] == WORKLOADS["c2"]["B"] and e == 2 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+    avg_ms = _time_graph([r[1] for r in calls], stream, reps)
+    tot_bytes, tot_flops = sum(w[0] for w in work), sum(w[1] for w in work)
+    classes = {}
+    for cls in ("root causal", "branch step", "tree pass"):
+        idx = [i for i, r in enumerate(calls) if _launch_class(r[2]) == cls]
+        if idx:
+            ms = _time_graph([calls[i][1] for i in idx], stream, reps)
+            b, f = sum(work[i][0] for i in idx) / len(idx), sum(work[i][1] for i in idx) / len(idx)
+            classes[cls] = {"launches_per_step": len(idx), "avg_launch_us": round(1e3 * ms, 2), "GBps": round(b / ms / 1e6, 1),
+                            "TFLOPs": round(f / ms / 1e9, 2)}
     achieved = tot_bytes / n / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "branch_attn_fwd_kernel (bg_branch_attn_fwd): one step's launch mix (root causal / branch step / tree pass)",
+    traffic, src = _pmc_traffic(f"r2_pmc_attn_{kind}_{workload_key}.json", n) if dtype_name == "bf16" else (None, None)
+    entry = "bg_branch_attn_fwd (branch_attn_fwd_kernel / _split_kernel)" if kind == "fwd" else \
+        "bg_branch_attn_bwd (its dq, dkv and slot-gradient kernels per launch)"
+    tf = tot_flops / n / (avg_ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": f"{entry}: one train step's recorded launch mix, replayed from a HIP graph",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/r1_f_pmc_attn_fwd.json (rocprofv3 --pmc passes over benchmarks/attn_mix.py)" if traffic else None,
-            "algorithmic_bytes_per_launch": tot_bytes / n, "avg_launch_ms": avg_ms, "launches_per_step": n,
-            "mfma": {"achieved_tflops": tot_flops / n / (avg_ms * 1e-3) / 1e12, "peak_tflops": 2500.0 if e == 2 else 157.3,
+            "traffic_source": src, "algorithmic_bytes_per_launch": tot_bytes / n, "avg_launch_ms": avg_ms, "launches_per_step": n,
+            "by_class": classes,
+            "mfma": {"achieved_tflops": tf, "peak_tflops": MFMA_PEAK_TFLOPS[dtype_name], "frac": tf / MFMA_PEAK_TFLOPS[dtype_name],
                      "note": "arithmetic intensity 2*Q_vis/e flop/B is far below the ridge at these shapes: HBM is the binding roof (SURVEY.md §8d)"}}
 
 
 def adam_roofline(optims):
-    """Roofline of bg_adam_step (adam_step_kernel), the hand-written kernel with the largest share of a step's GPU time
-    (profiles/r1_n_bench_c2_by_class.txt): two launches per step, one per model.  `optims` hold the (start, end) HIP events
+    """bg_adam_step (adam_step_kernel): two launches per step, one per model.  `optims` hold the (start, end) HIP events
     branchgan.optim.ArenaAdam.step recorded around every launch INSIDE the timed region, on the stream it launched on.
     Algorithmic bytes per launch = 34 B per parameter slot of the arena (read p, g, m, v fp32; write p, m, v fp32, the bf16
     weight copy and the zeroed gradient), DESIGN.md."""
@@ -172,14 +184,33 @@ def adam_roofline(optims):
             "algorithmic_bytes_per_launch": nbytes / launches, "avg_launch_ms": avg_ms, "launches_per_step": len(optims)}
 
 
-def cpu_baseline(workload, sample_batch, dtype_note):
+def host_cpu():
+    """(threads this process may use, CPU model string, CPUs the host reports).  The GPU box gives a one-GPU job a 16-CPU share
+    of a much larger machine and exports OMP_NUM_THREADS accordingly: that share is what the baseline runs on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = min(avail, int(os.environ.get("OMP_NUM_THREADS", str(avail))))
+    return max(threads, 1), model, os.cpu_count()
+
+
+def cpu_baseline(workload, sample_batch):
     """The oracle (CPU restatement of the reference path, plain PyTorch fp32) on a bounded sample of the same workload:
-    one step (forward of the whole GAN step + both backwards) at a reduced batch, timed on this host's cores."""
+    whole steps (forward of the GAN step + both backwards) at a reduced batch, timed on this host's cores."""
     from branchgan import configs
     from oracle import gan as OG, models as OM
     from branchgan import gan
     torch.manual_seed(0)
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    threads, model_name, host_cpus = host_cpu()
     torch.set_num_threads(threads)
     model = gan.GannSetup(workload["gen"], workload["disc"])
     sd = {k: v.detach().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
@@ -201,8 +232,105 @@ def cpu_baseline(workload, sample_batch, dtype_note):
             v.grad = None
         steps += 1
     dt = time.time() - t0
-    return {"value": steps * sample_batch * S / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+    return {"value": steps * sample_batch * S / dt, "unit": "tokens/s", "cores": threads, "kind": "port", "cpu_model": model_name,
+            "host_cpus": host_cpus,
             "sample": f"{steps} step(s) of the same workload at batch {sample_batch} (fwd + both bwd, no optimizer), fp32, {dt:.1f} s"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def sampling_cases(rows, V, dev):
+    """The seven cases of the sweep on resident inputs: (name, launch, algorithmic bytes, kernel family)."""
+    from branchgan import ops
+    g = torch.Generator(device=dev).manual_seed(2)
+    probs = torch.softmax(3.0 * torch.randn(rows, V, device=dev, generator=g), -1)
+    noise = -torch.log(torch.rand(rows, V, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) + 1e-14)
+    blocked = torch.randint(0, V, (rows, 1), device=dev, generator=g)
+    cases = [(f"TOP_K n={n}", lambda n=n: ops.topn_select(probs, n, blocked=blocked), rows * V * 4 + rows * n * 12, "topn") for n in (1, 4, 16)]
+    cases += [(f"SAMPLE_NO_REPLACEMENT n={n}", lambda n=n: ops.topn_select(probs, n, noise=noise, blocked=blocked), 2 * rows * V * 4 + rows * n * 12, "topn")
+              for n in (1, 4)]
+    cases += [(f"TOP_P p={p} n=4", lambda p=p: ops.topp_select(probs, 4, noise, p, blocked=blocked), 2 * rows * V * 4 + rows * 4 * 12, "topp")
+              for p in (0.5, 0.9)]
+    return cases, probs, noise
+
+
+def sampling_sweep(args):
+    """BASELINE configs[4]: the per-step branch sampling over the vocabulary at batch 64 x 128 rows, V = 50304 (SURVEY.md §8d:
+    TOP_K n in {1,4,16}; TOP_P p in {0.5,0.9}, n = 4; SAMPLE_NO_REPLACEMENT n in {1,4}).  A "step" = one pass of the whole sweep
+    over the resident (rows, V) probabilities and noise.  Algorithmic bytes per case: one read of the scores (+ one of the noise) +
+    rows * n * 12 bytes of output."""
+    from oracle import sampling as OS
+    wl = WORKLOADS["c5"]
+    rows, V = wl["rows"], wl["V"]
+    dev = torch.device("cuda", 0)
+    cases, probs, noise = sampling_cases(rows, V, dev)
+    for _ in range(args.warmup):
+        for _, fn, _, _ in cases:
+            fn()
+    torch.cuda.synchronize()
+    per_case = {name: [] for name, *_ in cases}
+    t_wall = time.perf_counter()
+    for _ in range(args.steps):
+        for name, fn, _, _ in cases:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            fn()
+            t1.record()
+            per_case[name].append((t0, t1))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_wall
+    table, groups = {}, {"topn": [0.0, 0.0], "topp": [0.0, 0.0]}
+    for name, _, nbytes, grp in cases:
+        ms = sum(a.elapsed_time(b) for a, b in per_case[name]) / len(per_case[name])
+        table[name] = {"ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "hbm_frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 3)}
+        groups[grp][0] += nbytes
+        groups[grp][1] += ms
+
+    def roof(grp, kernel, pmc):
+        b, ms = groups[grp]
+        n = sum(1 for c in cases if c[3] == grp)
+        traffic, src = _pmc_traffic(pmc, None)
+        ach = b / ms / 1e6
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": b / n, "avg_launch_ms": ms / n}
+    out = {"metric": "branch sampling sweep rows/sec (top-k / top-p / no-replacement over a 50k vocabulary)",
+           "value": rows * len(cases) * args.steps / elapsed, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "config": {"workload": wl["name"], "rows": rows, "vocab": V, "inputs": "probs = softmax(3 N(0,1)), noise = -log(U + 1e-14), resident in HBM"},
+           "roofline": roof("topn", "topn_partial_kernel (bg_topn_select): the five TOP_K / SAMPLE_NO_REPLACEMENT cases of the sweep", "r2_pmc_topn.json"),
+           "roofline_topp": roof("topp", "topp kernels (bg_topp_select): the two TOP_P cases of the sweep", "r2_pmc_topp.json"),
+           "cases": table}
+    if not args.no_cpu_baseline:
+        threads, model_name, host_cpus = host_cpu()
+        torch.set_num_threads(threads)
+        sub = 256
+        p_cpu, n_cpu = probs[:sub].cpu().unsqueeze(0), noise[:sub].cpu().unsqueeze(0)      # the oracle's (B, T, V) layout
+        t0, done = time.time(), 0
+        while done < 1 or time.time() - t0 < 10.0:
+            for n in (1, 4, 16):
+                OS.top_n(p_cpu, n)
+            for n in (1, 4):
+                OS.sample_without_replacement(p_cpu, n, n_cpu)
+            for p in (0.5, 0.9):
+                OS.sample_without_replacement(OS.top_p_filter(p_cpu, p), 4, n_cpu)
+            done += 1
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": done * sub * len(cases) / dt, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": model_name,
+                               "host_cpus": host_cpus, "sample": f"{done} pass(es) of the same sweep over the first {sub} rows (the reference's argsort path), {dt:.1f} s"}
+    print(json.dumps(out))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def measure_steps(step, steps, warmup, fence, arena_optims):
+    for i in range(warmup):
+        step(i)
+    for o in arena_optims:
+        o.timing = []
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        d, g = step(warmup + i)
+    fence()
+    return time.perf_counter() - t0, d, g
 
 
 def main():
@@ -215,6 +343,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 timing of the same workload")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="hipBLASLt default heuristics instead of the recorded TunableOp choices")
     args = ap.parse_args()
@@ -225,8 +354,10 @@ def main():
         if os.path.exists(probe):
             import ctypes
             ctypes.CDLL(probe).install_all_thread_dump(int(float(os.environ["BRANCHGAN_BENCH_WATCHDOG"])) - 3)
+    if args.workload == "c5":
+        return sampling_sweep(args)
 
-    from branchgan import ops, training
+    from branchgan import configs, ops, training
     tuned = (not args.no_tuned_gemm) and training.use_tuned_gemms()
     rank, world, local = training.init_data_parallel()
     if world != args.gpus and rank == 0:
@@ -236,24 +367,10 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
-    model, conf, rl, g_opt, d_opt = build(wl, device)
-    from branchgan import configs
     V = configs.LMConfig.from_any(wl["gen"]).vocab_size
     B, S = wl["B"], wl["S"]
     n_batches = 16
     data = zipf_ids(n_batches * B, S, V, 1234 + rank).view(n_batches, B, S).to(device)
-    use_amp = args.dtype == "bf16"
-
-    def eager_step(i):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
-            return training.train_step(model, data[i % n_batches], conf, g_opt, d_opt, i, 9999, rl)
-
-    if args.eager:
-        step = eager_step
-    else:
-        from branchgan.graphs import GraphedTrainStep
-        graphed = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, torch.bfloat16 if use_amp else None)
-        step = lambda i: graphed.step(data[i % n_batches], i)
 
     def fence():
         torch.cuda.synchronize()
@@ -261,55 +378,83 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    ops.TIMING = {}
-    arena_optims = [o.optimizer for o in (g_opt, d_opt) if hasattr(o.optimizer, "timing")]
-    for o in arena_optims:
-        o.timing = []
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        d, g = step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    adam = adam_roofline(arena_optims)
-    for o in arena_optims:
-        o.timing = None
-    if not args.eager:
-        graphed.check_nan()
-        for i in range(3):      # per-kernel HIP-event timing needs eager launches (events cannot sit inside a captured graph)
-            eager_step(args.warmup + args.steps + i)
-    kernels = ops.timing_summary()
-    ops.TIMING = None
+    def run(dtype_name, steps, warmup, with_rooflines):
+        """Builds the models fresh and times `steps` steps; -> (elapsed s, final losses, roofline objects)."""
+        use_amp = dtype_name == "bf16"
+        model, conf, rl, g_opt, d_opt = build(wl, device)
+
+        def eager_step(i):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
+                return training.train_step(model, data[i % n_batches], conf, g_opt, d_opt, i, 9999, rl)
+        graphed = None
+        if args.eager:
+            step = eager_step
+        else:
+            from branchgan.graphs import GraphedTrainStep
+            graphed = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, torch.bfloat16 if use_amp else None)
+            step = lambda i: graphed.step(data[i % n_batches], i)
+        arena_optims = [o.optimizer for o in (g_opt, d_opt) if hasattr(o.optimizer, "timing")]
+        elapsed, d, g = measure_steps(step, steps, warmup, fence, arena_optims)
+        if graphed is not None:
+            graphed.check_nan()
+        losses = {"gen": float(g["loss"].detach()), "disc": float(d["loss"].detach())}
+        roofs = {}
+        if with_rooflines:
+            roofs["adam"] = adam_roofline(arena_optims)
+        for o in arena_optims:
+            o.timing = None
+        del d, g
+        if with_rooflines and rank == 0:
+            ops.TIMING = {}
+            rec = record_attention_launches(eager_step, warmup + steps)      # one eager step: every attention launch it makes
+            roofs["eager_event_ms"] = {k: {"launches": v[0], "avg_ms": round(v[1], 4)} for k, v in sorted(ops.timing_summary().items())}
+            ops.TIMING = None
+            roofs["bwd"] = attention_roofline(rec, "bwd", dtype_name, device, args.workload)
+            roofs["fwd"] = attention_roofline(rec, "fwd", dtype_name, device, args.workload)
+            del rec
+        elif with_rooflines and world > 1:
+            eager_step(warmup + steps)       # keeps this rank's collectives in step with rank 0's recorded eager step
+        return elapsed, losses, roofs
+
+    main_dtype = "bf16" if args.dtype == "bf16" else "f32"
+    elapsed, losses, roofs = run(main_dtype, args.steps, args.warmup, True)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    other = None
+    if world == 1 and not args.no_fp32 and main_dtype == "bf16":      # the reference's shipped config is fp32: the same workload in fp32 beside it
+        torch.cuda.empty_cache()
+        n32 = max(3, args.steps // 2)
+        e32, l32, _ = run("f32", n32, 2, False)
+        other = {"dtype": "f32", "ms_per_step": 1000.0 * e32 / n32, "value": B * S * n32 / e32, "unit": "tokens/s", "steps": n32, "warmup": 2,
+                 "final_losses": l32}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    use_amp = main_dtype == "bf16"
     ms = 1000.0 * elapsed / args.steps
     tokens = world * B * S * args.steps
-    attn = attention_forward_roofline(wl, device, torch.bfloat16 if use_amp else torch.float32)
     out = {
         "metric": "branch-GAN train tokens/sec (gen+disc fwd/bwd)", "value": tokens / elapsed, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if use_amp else "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": main_dtype, "data": "synthetic",
         "config": {"workload": wl["name"], "per_gpu_batch": B, "seq_len": S, "branch_points": wl["K"], "depth": wl["D"],
                    "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay of fwd+bwd; all-reduce and Adam eager",
                    "precision": "bf16 autocast, fp32 master weights and accumulation" if use_amp else "fp32",
-                   "weights": "random init", "gemm": "hipBLASLt, recorded TunableOp choices" if tuned else "hipBLASLt defaults", "final_losses": {"gen": float(g["loss"].detach()), "disc": float(d["loss"].detach())}},
-        # the dominant hand-written kernel by GPU time per step first; the attention forward mix (the dominant one before the
-        # optimizer moved into this library) stays beside it
-        "roofline": adam if adam is not None else attn,
-        "roofline_attention_fwd": attn,
-        "eager_event_ms": {k: {"launches": v[0], "avg_ms": round(v[1], 4)} for k, v in sorted(kernels.items())},   # includes host launch gaps
+                   "weights": "random init", "gemm": "hipBLASLt, recorded TunableOp choices" if tuned else "hipBLASLt defaults", "final_losses": losses},
+        # the dominant hand-written hot-path entry point: attention backward; the forward and the optimizer kernel beside it
+        "roofline": roofs.get("bwd") or roofs.get("fwd") or roofs.get("adam"),
+        "roofline_attention_fwd": roofs.get("fwd"),
+        "roofline_adam": roofs.get("adam"),
+        "eager_event_ms": roofs.get("eager_event_ms"),   # includes host launch gaps
     }
+    if other is not None:
+        out["fp32"] = other
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_batch, args.dtype)
+        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_batch)
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -518,10 +518,7 @@ def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True):
 def _attn_fwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse):
     path, path_len, max_path = ops.path_tables(paths, q5.device)
     sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
-    with ops._timed("branch_attn_fwd"):
-        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
-                                           ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                           C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+    ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
 
 
 def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv, dkt_in=None, dvt_in=None):
@@ -529,11 +526,7 @@ def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse,
     sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
     sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
     delta = torch.empty_like(lse)
-    with ops._timed("branch_attn_bwd"):
-        C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
-                                           ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                           C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), C.ptr(dkt_in), C.ptr(dvt_in),
-                                           ops._ptr_array(dsk), ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+    ops.attn_bwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse, do5, dq5, dkt, dvt, dkt_in, dvt_in, dsk, dsv, delta)
 
 
 def _heads_first(t, NQ, K):
@@ -630,10 +623,7 @@ class _PackedAttention(torch.autograd.Function):
             slots_k, slots_v = anc_k + own_k, anc_v + own_v
         path, path_len, max_path = ops.path_tables(paths, qkv.device)
         sh = ops._attn_shape(q5, kt, slots_k, spec["scale"], max_path, o5)
-        with ops._timed("branch_attn_fwd"):
-            C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
-                                               ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                               C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
         ctx.save_for_backward(qkv, att, lse, ctx_len, path, path_len, *([] if root else [kt, vt]), *anc_k, *anc_v)
         ctx.meta = (root, NQ, K, n_anc, spec["scale"], max_path)
         ctx.set_materialize_grads(False)
@@ -692,11 +682,7 @@ class _PackedAttention(torch.autograd.Function):
         delta = torch.empty_like(lse)
         sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
         sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
-        with ops._timed("branch_attn_bwd"):
-            C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q5), C.ptr(kt), C.ptr(vt), ops._ptr_array(slots_k),
-                                               ops._ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(o5),
-                                               C.ptr(lse), C.ptr(do5), C.ptr(dq5), C.ptr(dkt), C.ptr(dvt), C.ptr(dk_in), C.ptr(dv_in),
-                                               ops._ptr_array(dsk), ops._ptr_array(dsv), C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+        ops.attn_bwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse, do5, dq5, dkt, dvt, dk_in, dv_in, dsk, dsv, delta)
         if dk_out is not None:      # what the descendants' attention sent back to this node's keys / values
             dkview.add_(dk_out)
         if dv_out is not None:

@@ -232,6 +232,59 @@ def _unit_last(t):
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
+# bench.py sets this to a list for ONE eager step: every attention launch of the step is appended as
+# (kind, launch closure, shape struct, ctx_len, path_len, extra) with its tensors kept alive by the closure, so the step's
+# real launch mix - same shapes, strides, data - can be replayed from a HIP graph and timed with events.
+ATTN_RECORD = None
+
+
+def attn_fwd_launch(sh, q, kt, vt, slots_k, slots_v, ctx_len, path, path_len, out, lse):
+    """The one place bg_branch_attn_fwd is called from."""
+    ka, va = _ptr_array(slots_k), _ptr_array(slots_v)
+
+    def launch():
+        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(kt), C.ptr(vt), ka, va, C.ptr(ctx_len), C.ptr(path),
+                                           C.ptr(path_len), C.ptr(out), C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+    with _timed("branch_attn_fwd"):
+        launch()
+    if ATTN_RECORD is not None:
+        ATTN_RECORD.append(("fwd", launch, sh, ctx_len, path_len, (slots_k, slots_v, False)))
+
+
+def attn_bwd_launch(sh, q, kt, vt, slots_k, slots_v, ctx_len, path, path_len, out, lse, dout, dq, dkt, dvt, dk_in, dv_in, dsk, dsv, delta):
+    """The one place bg_branch_attn_bwd is called from."""
+    ka, va, dka, dva = _ptr_array(slots_k), _ptr_array(slots_v), _ptr_array(dsk), _ptr_array(dsv)
+
+    def launch():
+        C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(kt), C.ptr(vt), ka, va, C.ptr(ctx_len), C.ptr(path),
+                                           C.ptr(path_len), C.ptr(out), C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dkt), C.ptr(dvt),
+                                           C.ptr(dk_in), C.ptr(dv_in), dka, dva, C.ptr(delta), C.stream_ptr()), "bg_branch_attn_bwd")
+    with _timed("branch_attn_bwd"):
+        launch()
+    if ATTN_RECORD is not None:
+        ATTN_RECORD.append(("bwd", launch, sh, ctx_len, path_len, (slots_k, slots_v, dk_in is not None, dsk, dsv)))
+
+
+def attn_launch_work(sh, ctx_len, path_len, kind, has_text_in=False):
+    """Algorithmic bytes and FLOPs of one attention launch:
+    forward  bytes = visible K/V read once (the longest visible text prefix + every slot's K rows) + Q read + O write;
+             flops = 4 * Dh * (visible query-key pairs);
+    backward bytes = K, V read + dK, dV written (all S_text text rows and every slot) + Q, O, dO read + dQ written
+                     (+ the incoming text gradients when they are added in the kernel);  flops = 2.5 x forward."""
+    e = 4 if sh.dtype == C.BG_F32 else 2
+    ctx = torch.clamp(ctx_len.to(torch.int64), max=sh.S_text)
+    plen = path_len.to(torch.int64)[:sh.NQ] if sh.max_path else torch.zeros(sh.NQ, dtype=torch.int64)
+    pairs = sh.NQ * int(ctx.sum()) + sh.K * int(plen.sum())
+    q_bytes = sh.B * sh.H * sh.NQ * sh.K * sh.Dh * e
+    flops = 4.0 * sh.Dh * sh.H * sh.B * pairs
+    if kind == "fwd":
+        kv_bytes = 2 * sh.B * sh.H * sh.Dh * (int(ctx.max()) + sh.n_slots * sh.K) * e
+        return kv_bytes + 2 * q_bytes, flops
+    kv_bytes = 2 * sh.B * sh.H * sh.Dh * (sh.S_text + sh.n_slots * sh.K) * e
+    text_bytes = 2 * sh.B * sh.H * sh.Dh * sh.S_text * e
+    return 2 * kv_bytes + 4 * q_bytes + (text_bytes if has_text_in else 0), 2.5 * flops
+
+
 class _BranchAttention(torch.autograd.Function):
     """own_k / own_v (optional, (B,H,NQ,K,Dh)): the keys / values of the query nodes themselves, ONE tensor for all nodes.
     They become slots n_slots .. n_slots + NQ - 1 as views made in here, so autograd sees one input and backward returns one
@@ -263,10 +316,7 @@ class _BranchAttention(torch.autograd.Function):
         out = torch.empty((B, NQ, K, H, Dh), dtype=q.dtype, device=q.device).permute(0, 3, 1, 2, 4)
         lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=q.device)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
-        with _timed("branch_attn_fwd"):
-            C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
-                                               _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
-                                               C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        attn_fwd_launch(sh, q, k_text, v_text, slots_k, slots_v, ctx_len, path, path_len, out, lse)
         has_own = own_k is not None
         ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots[:n_slots], *slots[n_slots:],
                               *((own_k, own_v) if has_own else ()))
@@ -303,12 +353,8 @@ class _BranchAttention(torch.autograd.Function):
         delta = torch.empty_like(lse)
         sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
         sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq.stride()[:4]
-        with _timed("branch_attn_bwd"):
-            C.check(C.lib().bg_branch_attn_bwd(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), C.ptr(v_text), _ptr_array(slots_k),
-                                               _ptr_array(slots_v), C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out),
-                                               C.ptr(lse), C.ptr(dout), C.ptr(dq), C.ptr(dk_text), C.ptr(dv_text), None, None,
-                                               _ptr_array(dks), _ptr_array(dvs), C.ptr(delta), C.stream_ptr()),
-                    "bg_branch_attn_bwd")
+        attn_bwd_launch(sh, q, k_text, v_text, slots_k, slots_v, ctx_len, path, path_len, out, lse, dout, dq, dk_text, dv_text, None, None,
+                        dks, dvs, delta)
         return (dq, dk_text, dv_text, None, None, None, None, None, None, d_own_k, d_own_v, *d_anc_k, *d_anc_v)
 
 
