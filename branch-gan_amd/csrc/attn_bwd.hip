@@ -460,9 +460,28 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) 
   }
 }
 
+template <typename T> bool launch_bwd_split(const AttnArgs& a, hipStream_t st);     // attn_bwd_split.hip
+
+template <typename T>
+static void launch_slots(const AttnArgs& a, hipStream_t st) {
+  const bg_attn_shape& sh = a.sh;
+  if (sh.n_slots == 0) return;
+  const dim3 grid_s((unsigned)sh.n_slots, (unsigned)(sh.B * sh.H)), block(256);
+  switch (sh.Dh) {
+    case 32: hipLaunchKernelGGL((branch_attn_bwd_slots_kernel<T, 32>), grid_s, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((branch_attn_bwd_slots_kernel<T, 64>), grid_s, block, 0, st, a); break;
+    case 128: hipLaunchKernelGGL((branch_attn_bwd_slots_kernel<T, 128>), grid_s, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((branch_attn_bwd_slots_kernel<T, 256>), grid_s, block, 0, st, a); break;
+  }
+}
+
 template <typename T>
 static void launch_bwd(const AttnArgs& a, hipStream_t st) {
   const bg_attn_shape& sh = a.sh;
+  if (launch_bwd_split<T>(a, st)) {          // dq (+ delta) and dkv with the other axis split over the waves
+    launch_slots<T>(a, st);
+    return;
+  }
   const dim3 block(256);
   const dim3 grid_q((unsigned)cdiv((int64_t)sh.NQ * sh.K, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));
   const dim3 grid_k((unsigned)cdiv((int64_t)sh.S_text, ATT_WAVES * ATT_TILE), (unsigned)(sh.B * sh.H));

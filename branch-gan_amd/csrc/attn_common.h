@@ -141,6 +141,19 @@ template <typename T, int DH, int NTHREADS> struct TileRegs {
       if (c < CHUNKS && row0 + r < nrows) v[i] = *(const V*)(g + (int64_t)(row0 + r) * rs + d0);
     }
   }
+  // the same for rows that are (n, k)-indexed (queries, outputs and their gradients): row rr = row0 + r lives at
+  // g + (rr / K) * sn + (rr % K) * sk
+  __device__ __forceinline__ void load_nk(const T* g, int64_t sn, int64_t sk, int K, int nrows, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * NTHREADS;
+      const int r = c / (DH / VEC), d0 = (c % (DH / VEC)) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = (T)0.0f;
+      const int rr = row0 + r;
+      if (c < CHUNKS && rr < nrows) v[i] = *(const V*)(g + (int64_t)(rr / K) * sn + (int64_t)(rr % K) * sk + d0);
+    }
+  }
   template <bool ROW, bool COL>
   __device__ __forceinline__ void store(T* lds_row, T* lds_col, int tid) const {
 #pragma unroll
@@ -290,6 +303,17 @@ template <int DH> struct RowFrag<bf16_t, DH> {
       for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.0f;
       return p ? *(const bf16x8*)(p + 16 * t + 8 * h) : z;
     }
+  }
+};
+
+// The same fragments for a row that sits in an LDS tile (row layout) for the kernel's whole life: nothing is kept, get()
+// reads where the product needs it.
+template <typename T, int DH> struct LdsRowFrag {
+  const T* p;
+  __device__ __forceinline__ void load(const T* row) { p = row; }
+  __device__ __forceinline__ auto get(int t, int h) const {
+    if constexpr (sizeof(T) == 4) return p[2 * t + h];
+    else return *(const bf16x8*)(p + 16 * t + 8 * h);
   }
 };
 
