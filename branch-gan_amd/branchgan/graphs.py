@@ -119,8 +119,17 @@ class GraphedTrainStep:
         # exponential noise of the race techniques: persistent tensors, one per sampling call of a step, refreshed before a replay
         self._noise, self._noise_cursor, self._user_noise = [], 0, model.noise_fn
         self._refresh_sparse(example_ids)
-        side = torch.cuda.Stream(device=dev)
+        # ONE side stream per model, shared by every graphed step built on it (the training loop builds one per tree depth):
+        # autograd binds a parameter's AccumulateGrad node to the stream of its first use and keeps the node while any captured
+        # graph of the model lives, so a second graphed step warmed up on ANOTHER stream would trip the guard below
+        side = model.__dict__.get("_graph_stream")
+        if side is None or side.device != dev:
+            side = torch.cuda.Stream(device=dev)
+            model.__dict__["_graph_stream"] = side
         self.stream = side
+        if os.environ.get("BRANCHGAN_DEBUG_STREAMS"):
+            print(f"[streams] side {side.cuda_stream:#x}  g_opt.stream {getattr(getattr(generatorOptim, 'stream', None), 'cuda_stream', 0):#x}  "
+                  f"d_opt.stream {getattr(getattr(discriminatorOptim, 'stream', None), 'cuda_stream', 0):#x}  current {torch.cuda.current_stream().cuda_stream:#x}", flush=True)
         self._own_stream = os.environ.get("BRANCHGAN_REPLAY_STREAM", "0") == "1"
         side.wait_stream(torch.cuda.current_stream())
         if warmup < 1:
@@ -129,14 +138,21 @@ class GraphedTrainStep:
         model.noise_fn = self._static_noise
         try:
             import warnings
-            with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:   # eager warm-up: builds arenas, caches, workspaces
-                warnings.simplefilter("always")
-                for i in range(warmup):
-                    self._refresh_noise()
-                    self._forward_backward()
-                    self._finish(i)
-                if saved is not None:
-                    self._restore(saved)
+            # the warning looked for below is a warn-ONCE in libtorch: without set_warn_always a second graphed step of the same
+            # process would never see it
+            warn_always = torch.is_warn_always_enabled()
+            torch.set_warn_always(True)
+            try:
+                with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:   # eager warm-up: builds arenas, caches, workspaces
+                    warnings.simplefilter("always")
+                    for i in range(warmup):
+                        self._refresh_noise()
+                        self._forward_backward()
+                        self._finish(i)
+                    if saved is not None:
+                        self._restore(saved)
+            finally:
+                torch.set_warn_always(warn_always)
             for w in caught:
                 # autograd keeps a parameter's AccumulateGrad node alive, bound to the stream it was created on, for as long as an
                 # autograd graph refers to it.  A capture would then make the capture stream synchronise with that other stream;

@@ -6,7 +6,7 @@
 //   3. slots kernel   per-row VALU: dK/dV of each branch slot = sum over the query nodes whose path holds it.
 // Gradients of the reference ops cited in attn_fwd.hip (autograd of NeoXNonResidualAttention.py:183-232 /
 // NonResidualAttention.py:119-172).  See include/branchgan.h: bg_branch_attn_bwd.
-#include "attn_common.h"
+#include "attn_bwd_slots.h"
 
 namespace bg {
 
@@ -331,136 +331,15 @@ static size_t attn_dkv_lds_bytes(int dtype, int Dh, int64_t n_queries) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// grid (n_slots, B*H), 256 threads: 8 lanes per branch point k, each lane owns DH/8 contiguous features.
-// The query nodes whose path holds this slot are listed in LDS first (all threads test one node each: ballot + popcount keep
-// them in ascending order, so the sums below are taken in a fixed order); the list is then walked four members at a time
-// with all their loads issued together - a walk over every node with a dependent load per test was 17 us of latency.
-template <typename T, int N>
-__device__ __forceinline__ void slot_load(float (&out)[N], const T* p, bool valid) {
-#pragma unroll
-  for (int c = 0; c < N / 4; ++c) {
-    if constexpr (sizeof(T) == 4) {
-      f32x4 raw = {0.f, 0.f, 0.f, 0.f};
-      if (valid) raw = *(const f32x4*)(p + 4 * c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[4 * c + j] = raw[j];
-    } else {
-      float x[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        const bf16x4 raw = *(const bf16x4*)(p + 4 * c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = (float)raw[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[4 * c + j] = x[j];
-    }
-  }
-}
-
-template <typename T, int N>
-__device__ __forceinline__ void slot_store(T* p, const float (&v)[N]) {
-#pragma unroll
-  for (int c = 0; c < N / 4; ++c) {
-    if constexpr (sizeof(T) == 4) {
-      f32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = v[4 * c + j];
-      *(f32x4*)(p + 4 * c) = o;
-    } else {
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[4 * c + j];
-      *(bf16x4*)(p + 4 * c) = o;
-    }
-  }
-}
-
+// grid (n_slots, B*H), 256 threads: the slot rows' dK / dV (attn_bwd_slots.h)
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) {
-  constexpr int LPR = 8, PER = DH / LPR, U = PER <= 8 ? 4 : (PER <= 16 ? 2 : 1);   // U: members whose loads are in flight together
-  static_assert(PER % 4 == 0, "slot kernel: four features per vector");
   __shared__ int s_members[256];
   __shared__ int s_count[ATT_WAVES];
-  const bg_attn_shape& sh = a.sh;
-  const int slot = blockIdx.x, bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
-  const int tid = threadIdx.x, sub = tid % LPR, lane = tid & 63, wave = tid >> 6;
-  const T* kslot = nullptr;
-  const T* vslot = nullptr;
-  T* dkslot = nullptr;
-  T* dvslot = nullptr;
-  for (int sidx = 0; sidx < sh.n_slots; ++sidx)
-    if (sidx == slot) { kslot = (const T*)a.k_slots[sidx]; vslot = (const T*)a.v_slots[sidx]; dkslot = (T*)a.dk_slots[sidx]; dvslot = (T*)a.dv_slots[sidx]; }
-
-  for (int k0 = 0; k0 < sh.K; k0 += 256 / LPR) {
-    const int kq = k0 + tid / LPR;
-    const bool valid = kq < sh.K;
-    const int64_t soff = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)(valid ? kq : 0) * sh.s_sk + sub * PER;
-    float kk[PER], vv[PER], dk[PER], dv[PER];
-    slot_load<T, PER>(kk, kslot + soff, valid);
-    slot_load<T, PER>(vv, vslot + soff, valid);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
-
-    for (int n0 = 0; n0 < sh.NQ; n0 += 256) {
-      const int nt = n0 + tid;
-      bool member = false;
-      if (nt < sh.NQ) {
-        const int plen = a.path_len[nt];
-        for (int p = 0; p < plen; ++p) member |= (a.path[nt * sh.max_path + p] == slot);
-      }
-      const unsigned long long bal = __ballot(member);
-      __syncthreads();  // the previous chunk's list is no longer read
-      if (lane == 0) s_count[wave] = __popcll(bal);
-      __syncthreads();
-      int base = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < ATT_WAVES; ++w) { const int c = s_count[w]; base += (w < wave) ? c : 0; total += c; }
-      if (member) s_members[base + __popcll(bal & ((1ull << lane) - 1ull))] = nt;
-      __syncthreads();
-
-      for (int m0 = 0; m0 < total; m0 += U) {
-        float qq[U][PER], dd[U][PER], ls[U], de[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool on = valid && (m0 + u < total);
-          const int n = s_members[min(m0 + u, total - 1)];
-          const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)(valid ? kq : 0) * sh.q_sk + sub * PER;
-          const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)(valid ? kq : 0) * sh.o_sk + sub * PER;
-          const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + (valid ? kq : 0);
-          slot_load<T, PER>(qq[u], (const T*)a.q + qoff, on);
-          slot_load<T, PER>(dd[u], (const T*)a.dout + ooff, on);
-          ls[u] = on ? a.lse[stat] : 0.f;
-          de[u] = on ? a.delta[stat] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (m0 + u >= total) break;  // workgroup-uniform
-          float sdot = 0.f, pdot = 0.f;
-#pragma unroll
-          for (int j = 0; j < PER; ++j) {
-            sdot = fmaf(qq[u][j], kk[j], sdot);
-            pdot = fmaf(dd[u][j], vv[j], pdot);
-          }
-#pragma unroll
-          for (int o = 1; o < LPR; o <<= 1) { sdot += __shfl_xor(sdot, o); pdot += __shfl_xor(pdot, o); }
-          const float pw = valid ? __expf(sdot * sh.scale - ls[u]) : 0.f;
-          const float ds = valid ? pw * (pdot - de[u]) * sh.scale : 0.f;
-#pragma unroll
-          for (int j = 0; j < PER; ++j) {
-            dk[j] = fmaf(ds, qq[u][j], dk[j]);
-            dv[j] = fmaf(pw, dd[u][j], dv[j]);
-          }
-        }
-      }
-    }
-    if (valid) {
-      slot_store<T, PER>(dkslot + soff, dk);
-      slot_store<T, PER>(dvslot + soff, dv);
-    }
-  }
+  bwd_slot_rows<T, DH, false>(a, s_members, s_count, blockIdx.x, blockIdx.y);
 }
 
-template <typename T> bool launch_bwd_split(const AttnArgs& a, hipStream_t st);     // attn_bwd_split.hip
+template <typename T> int launch_bwd_split(const AttnArgs& a, hipStream_t st);      // attn_bwd_split.hip: 0 no, 1 slots left, 2 all
 
 template <typename T>
 static void launch_slots(const AttnArgs& a, hipStream_t st) {
@@ -478,8 +357,8 @@ static void launch_slots(const AttnArgs& a, hipStream_t st) {
 template <typename T>
 static void launch_bwd(const AttnArgs& a, hipStream_t st) {
   const bg_attn_shape& sh = a.sh;
-  if (launch_bwd_split<T>(a, st)) {          // dq (+ delta) and dkv with the other axis split over the waves
-    launch_slots<T>(a, st);
+  if (const int done = launch_bwd_split<T>(a, st)) {   // the other axis split over the waves; one launch where it fits
+    if (done == 1) launch_slots<T>(a, st);
     return;
   }
   const dim3 block(256);

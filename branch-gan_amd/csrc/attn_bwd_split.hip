@@ -11,7 +11,7 @@
 // Same mathematics and the same per-element operations as attn_bwd.hip; only the summation is regrouped.
 #include <stdlib.h>
 
-#include "attn_common.h"
+#include "attn_bwd_slots.h"
 
 namespace bg {
 
@@ -23,12 +23,12 @@ __device__ unsigned long long g_attn_trace[2][BG_TRACE_WAVES][16];
 #define BG_TRACE(kind, slot)                                                                       \
   do {                                                                                             \
     __builtin_amdgcn_s_waitcnt(0);                                                                 \
-    const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);    \
+    const unsigned w_ = (unsigned)(bh * (int)n_xtiles + tile_x) * ATT_WAVES + (threadIdx.x >> 6);   \
     if ((threadIdx.x & 63) == 0 && w_ < BG_TRACE_WAVES) g_attn_trace[kind][w_][slot] = wall_clock64(); \
   } while (0)
 #define BG_TRACE_VAL(kind, slot, v)                                                                \
   do {                                                                                             \
-    const unsigned w_ = (blockIdx.y * gridDim.x + blockIdx.x) * ATT_WAVES + (threadIdx.x >> 6);    \
+    const unsigned w_ = (unsigned)(bh * (int)n_xtiles + tile_x) * ATT_WAVES + (threadIdx.x >> 6);   \
     if ((threadIdx.x & 63) == 0 && w_ < BG_TRACE_WAVES) g_attn_trace[kind][w_][slot] = (v);        \
   } while (0)
 #else
@@ -90,20 +90,19 @@ __device__ __forceinline__ void store_vec(T* p, const float (&acc)[PER], const T
 // ---------------------------------------------------------------------------------------------------
 // dQ (and delta): one 32-query tile per workgroup, the key tiles dealt round-robin to the four waves.
 template <typename T, int DH>
-__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_split_kernel(AttnArgs a) {
+__device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int tile_x, int bh) {
   using SL = BwdSplitLds<T, DH, DH>;
   constexpr int NDT = DH / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int R = sh.NQ * sh.K;
+  [[maybe_unused]] const int n_xtiles = (R + ATT_TILE - 1) / ATT_TILE;
   BG_TRACE(0, 0);
   BG_TRACE(0, 1);
   T* k_row = (T*)(smem + wave * SL::WAVE_BYTES);
   T* v_row = (T*)(smem + wave * SL::WAVE_BYTES + SL::TILE_BYTES);
-  const BlockXY blk = xcd_block();
-  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
-  const int R = sh.NQ * sh.K;
-  const int rq = blk.x * ATT_TILE + (lane & 31);
+  const int b = bh / sh.H, hh = bh % sh.H;
+  const int rq = tile_x * ATT_TILE + (lane & 31);
   const bool valid = rq < R;
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
   const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)kq * sh.q_sk;
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_sp
     T* q_l = (T*)(smem + SL::STAGE_BYTES);
     T* do_l = (T*)(smem + SL::STAGE_BYTES + SL::TILE_BYTES);
     float* delta_l = (float*)(smem + SL::STAGE_BYTES + 2 * SL::TILE_BYTES);
-    const int row0 = blk.x * ATT_TILE;
+    const int row0 = tile_x * ATT_TILE;
     TileRegs<T, DH, 256> gq, gdo, go;
     gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, row0, tid);
     gdo.load_nk((const T*)a.dout + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh, sh.o_sn, sh.o_sk, sh.K, R, row0, tid);
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_sp
   // branch keys: path entries wave, wave + 4, ...
   for (int p = wave; p < sh.max_path; p += ATT_WAVES) {
     const bool act = p < plen;
-    const int slot = act ? a.path[n * sh.max_path + p] : 0;
+    const int slot = a.path[n * sh.max_path + p];        // in bounds for every p < max_path: no wait on path_len first
     const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
     const T* kr = nullptr;
     const T* vr = nullptr;
@@ -244,7 +243,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_sp
   {
     constexpr int PER = DH / 8;                          // thread -> query tid & 31, feature group tid >> 5
     const int qi = tid & 31, grp = tid >> 5;
-    const int rq2 = blk.x * ATT_TILE + qi;
+    const int rq2 = tile_x * ATT_TILE + qi;
     if (rq2 < R) {
       const int n2 = rq2 / sh.K, k2 = rq2 % sh.K;
       float acc[PER];
@@ -260,15 +259,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_sp
 // ---------------------------------------------------------------------------------------------------
 // dK / dV of the text rows: one 32-key tile per workgroup, the query tiles that reach it dealt round-robin to the four
 // waves.  [DT0, DT1) is the slice of d (in 32s) this launch accumulates: all of it up to DH = 128, two launches at 256.
-template <typename T, int DH, int DT0, int DT1>
-__global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_bwd_dkv_split_kernel(AttnArgs a) {
+// OWN_DELTA: delta = rowsum(dO o O) of a gathered query tile is worked out here, from its O rows, instead of being read from
+// a.delta (the one-launch backward, where the dQ workgroups that write a.delta run beside this one, not before it).
+template <typename T, int DH, int DT0, int DT1, bool OWN_DELTA>
+__device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int tile_x, int bh) {
   constexpr int DPASS = (DT1 - DT0) * 32;
   constexpr bool PREFETCH = DH >= 128;
   using SL = BwdSplitLds<T, DH, DPASS>;
   using L = Lds<T, DH>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  [[maybe_unused]] const int n_xtiles = (sh.S_text + ATT_TILE - 1) / ATT_TILE;
   BG_TRACE(1, 0);
   T* q_row_l = (T*)(smem + wave * SL::WAVE_BYTES);
   T* do_row_l = (T*)(smem + wave * SL::WAVE_BYTES + SL::TILE_BYTES);
@@ -277,11 +278,10 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   int* ctx_s = (int*)(delta_s + ATT_TILE);
   int* reach_s = (int*)(smem + SL::BYTES);               // one int per query tile, behind the staging / merge area
 
-  const BlockXY blk = xcd_block();
-  const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
+  const int b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
   const int n_qtiles = (R + ATT_TILE - 1) / ATT_TILE;
-  const int key0 = blk.x * ATT_TILE;
+  const int key0 = tile_x * ATT_TILE;
   const int key = key0 + (lane & 31);
   [[maybe_unused]] const bool kvalid = key < sh.S_text;
   [[maybe_unused]] const int64_t row_off = (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key * sh.t_ss;
@@ -291,25 +291,27 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   constexpr int PERW = ATT_TILE * CPR / 64;              // chunks per lane
   typedef typename TileRegs<T, DH, 64>::V Chunk;
   Chunk gq[PERW], gd[PERW];
+  [[maybe_unused]] Chunk go[OWN_DELTA ? PERW : 1];
   float g_lse = 0.f, g_delta = 0.f;
   int g_ctx = 0;
-  auto gather = [&](int tq) {
+  const T* q_head = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh;
+  const T* do_head = (const T*)a.dout + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh;
+  [[maybe_unused]] const T* o_head = (const T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh;
+  auto gather = [&](int tq) __attribute__((always_inline)) {
     const int q0 = tq * ATT_TILE;
 #pragma unroll
     for (int i = 0; i < PERW; ++i) {
       const int c = lane + i * 64;
       const int r = c / CPR, d0 = (c % CPR) * VEC;
-      const int rr = q0 + r;
-      const bool ok = rr < R;
-      const int nn = ok ? rr / sh.K : 0, kk = ok ? rr % sh.K : 0;
-      const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)nn * sh.q_sn + (int64_t)kk * sh.q_sk + d0;
-      const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)nn * sh.o_sn + (int64_t)kk * sh.o_sk + d0;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) { gq[i][j] = (T)0.0f; gd[i][j] = (T)0.0f; }
-      if (ok) {
-        gq[i] = *(const Chunk*)((const T*)a.q + qoff);
-        gd[i] = *(const Chunk*)((const T*)a.dout + ooff);
-      }
+      // rows past the end read the last row instead (no branch around the loads): their ctx is 0 below, which masks them
+      const int rr = min(q0 + r, R - 1);
+      const int nn = rr / sh.K, kk = rr % sh.K;
+      // 32-bit offsets inside one (batch, head) slice - checked on the host (slice_fits_32) - on a wave-uniform base
+      const unsigned qoff = (unsigned)nn * (unsigned)sh.q_sn + (unsigned)kk * (unsigned)sh.q_sk + (unsigned)d0;
+      const unsigned ooff = (unsigned)nn * (unsigned)sh.o_sn + (unsigned)kk * (unsigned)sh.o_sk + (unsigned)d0;
+      gq[i] = *(const Chunk*)(q_head + qoff);
+      gd[i] = *(const Chunk*)(do_head + ooff);
+      if constexpr (OWN_DELTA) go[i] = *(const Chunk*)(o_head + ooff);
     }
     const int rq = q0 + (lane & 31);
     const bool qv = rq < R;
@@ -317,13 +319,46 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     const int64_t stat = ((int64_t)bh * sh.NQ + nn) * sh.K + kk;
     g_ctx = qv ? min(a.ctx_len[kk], sh.S_text) : 0;      // 0 for rows past the end: masks everything
     g_lse = qv ? a.lse[stat] : 0.f;
-    g_delta = qv ? a.delta[stat] : 0.f;
+    if constexpr (!OWN_DELTA) g_delta = qv ? a.delta[stat] : 0.f;
+  };
+
+  // the gathered tile goes to this wave's staging area (row layout), with its rows' lse / ctx and delta
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PERW; ++i) {
+      const int c = lane + i * 64;
+      const int r = c / CPR, d0 = (c % CPR) * VEC;
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          q_row_l[r * L::RSTRIDE + d0 + j] = gq[i][j];
+          do_row_l[r * L::RSTRIDE + d0 + j] = gd[i][j];
+        }
+      } else {
+        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = gq[i];
+        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = gd[i];
+      }
+      if constexpr (OWN_DELTA) {                         // the CPR lanes that hold one row add up its dO . O
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) part = fmaf((float)gd[i][j], (float)go[i][j], part);
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (c % CPR == 0) delta_s[r] = part;
+      }
+    }
+    if (lane < ATT_TILE) {
+      lse_s[lane] = g_lse;
+      if constexpr (!OWN_DELTA) delta_s[lane] = g_delta;
+      ctx_s[lane] = g_ctx;
+    }
   };
 
   // One round of loads: the workgroup's K / V tile in whole row chunks (parked in LDS, see BwdSplitLds), the context
   // lengths behind the reach of every query tile (largest ctx_len among its 32 queries; 256 queries a step) and - before
   // the reach is known - a first query tile: tiles are dealt from the LAST one down (under a causal mask the late queries
-  // are the ones that see a key tile), so wave w bets on tile n_qtiles - 1 - w.
+  // are the ones that see a key tile), so wave w bets on tile n_qtiles - 1 - w and stages it at once (a tile held in
+  // registers across the barrier and the dealing was what pushed the kernel past three waves per SIMD).
   const int guess = n_qtiles - 1 - wave;
   typename std::conditional<SL::OWN, LdsRowFrag<T, DH>, RowFrag<T, DH>>::type kf, vf;
   if constexpr (SL::OWN) {
@@ -343,6 +378,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     if (guess >= 0) gather(guess);
     gk.template store<true, false>(k_l, nullptr, tid);
     gv.template store<true, false>(v_l, nullptr, tid);
+    if (guess >= 0) stage();
     BG_TRACE(1, 1);
     __syncthreads();
     kf.load(k_l + (lane & 31) * L::RSTRIDE);
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
       for (int o = 32; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
       if (lane == 0) reach_s[tq] = t;
     }
-    if (guess >= 0) gather(guess);
+    if (guess >= 0) { gather(guess); stage(); }
     BG_TRACE(1, 1);
     __syncthreads();
   }
@@ -365,12 +401,12 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   // This wave's tiles: every fourth of the tiles that reach key0, counted from the last tile down.  The eligible tiles
   // of 64 at a time are one ballot; walking it is scalar work.
   int chunk = (n_qtiles - 1) / 64, dealt = 0;
-  auto eligible = [&](int ch) -> unsigned long long {
+  auto eligible = [&](int ch) __attribute__((always_inline)) -> unsigned long long {
     const int idx = ch * 64 + lane;
     return __ballot(idx < n_qtiles && reach_s[idx < n_qtiles ? idx : 0] > key0);
   };
   unsigned long long elig = n_qtiles > 0 ? eligible(chunk) : 0ull;
-  auto next_mine = [&]() -> int {
+  auto next_mine = [&]() __attribute__((always_inline)) -> int {
     for (;;) {
       while (elig) {
         const int t = 63 - __builtin_clzll(elig);
@@ -392,35 +428,20 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
   int tq = next_mine();
-  bool have = tq == guess;                               // the bet was won: the tile is already on its way
+  bool staged = tq == guess;                             // the bet was won: the tile is in the staging area already
+  [[maybe_unused]] bool have = false;                    // (prefetch form) the tile is in the gather registers
   BG_TRACE(1, 3);
   [[maybe_unused]] unsigned long long my_tiles = 0;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   while (tq >= 0) {
     ++my_tiles;
-    if (!have) gather(tq);
+    if (!staged) {
+      if (!PREFETCH || !have) gather(tq);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
+      stage();
+    }
+    staged = false;
     have = false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
-#pragma unroll
-    for (int i = 0; i < PERW; ++i) {
-      const int c = lane + i * 64;
-      const int r = c / CPR, d0 = (c % CPR) * VEC;
-      if constexpr (sizeof(T) == 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          q_row_l[r * L::RSTRIDE + d0 + j] = gq[i][j];
-          do_row_l[r * L::RSTRIDE + d0 + j] = gd[i][j];
-        }
-      } else {
-        *(bf16x8*)(q_row_l + r * L::RSTRIDE + d0) = gq[i];
-        *(bf16x8*)(do_row_l + r * L::RSTRIDE + d0) = gd[i];
-      }
-    }
-    if (lane < ATT_TILE) {
-      lse_s[lane] = g_lse;
-      delta_s[lane] = g_delta;
-      ctx_s[lane] = g_ctx;
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     tq = next_mine();
     // Dh >= 128 runs one wave per SIMD whatever it does: the next tile's loads fly behind this tile's MFMAs.  Below that
@@ -492,6 +513,51 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   BG_TRACE_VAL(1, 7, my_tiles);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The kernels.  Two-launch form (dQ + delta, then dK / dV reading a.delta; the slot rows follow in attn_bwd.hip's kernel)
+// and the one-launch form, where every workgroup of the backward - key tiles, query tiles, slot rows - is in ONE grid and
+// whoever needs delta works it out from the O rows it gathers anyway.  At the BASELINE shapes a workgroup's life is a few
+// dependent memory round trips (3-4 us of loads around 1-3 us of MFMA work, benchmarks/probes/attn_trace.py): three launches
+// pay them one after the other, each with its own ramp and drain; one launch overlaps them.
+template <typename T, int DH>
+__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_split_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BlockXY blk = xcd_block();
+  bwd_dq_tile<T, DH>(a, smem, blk.x, blk.y);
+}
+
+template <typename T, int DH, int DT0, int DT1>
+__global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_bwd_dkv_split_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BlockXY blk = xcd_block();
+  bwd_dkv_tile<T, DH, DT0, DT1, false>(a, smem, blk.x, blk.y);
+}
+
+// grid.x = B*H * (key tiles + query tiles + slots).  The workgroups of one head share its Q, K, V, dO: they are given
+// block numbers that are congruent mod 8, i.e. one XCD and one L2 (blocks are dealt round-robin over the 8 XCDs), and
+// within a head the order is heaviest first - key tiles from 0 (under a causal mask tile 0 is reached by every query
+// tile), query tiles from the last one down, then the slot rows.
+template <typename T, int DH>
+__global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_bwd_one_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bg_attn_shape& sh = a.sh;
+  const int nq = (sh.NQ * sh.K + ATT_TILE - 1) / ATT_TILE, nk = (sh.S_text + ATT_TILE - 1) / ATT_TILE;
+  const int per_head = nk + nq + sh.n_slots, heads = sh.B * sh.H;
+  const int id = blockIdx.x;
+  int bh, item;
+  if (heads % 8 == 0) {
+    const int j = id / 8;
+    bh = (j / per_head) * 8 + id % 8;
+    item = j % per_head;
+  } else {
+    bh = id / per_head;
+    item = id % per_head;
+  }
+  if (item < nk) bwd_dkv_tile<T, DH, 0, DH / 32, true>(a, smem, item, bh);
+  else if (item < nk + nq) bwd_dq_tile<T, DH>(a, smem, nq - 1 - (item - nk), bh);
+  else bwd_slot_rows<T, DH, true>(a, (int*)smem, (int*)smem + 256, item - nk - nq, bh);
+}
+
 template <typename T, int DH, int DT0, int DT1>
 static void launch_dkv_split(const AttnArgs& a, dim3 grid, size_t reach_bytes, hipStream_t st) {
   constexpr size_t lds = BwdSplitLds<T, DH, (DT1 - DT0) * 32>::BYTES;
@@ -501,17 +567,29 @@ static void launch_dkv_split(const AttnArgs& a, dim3 grid, size_t reach_bytes, h
 }
 
 template <typename T, int DH>
-static void launch_split(const AttnArgs& a, hipStream_t st) {
+static int launch_split(const AttnArgs& a, bool one, hipStream_t st) {
   const bg_attn_shape& sh = a.sh;
   const int64_t R = (int64_t)sh.NQ * sh.K;
+  const size_t reach = (size_t)cdiv(R, ATT_TILE) * 4 + 16;
+  constexpr size_t lq = BwdSplitLds<T, DH, DH>::BYTES;
+  if constexpr (DH <= 128) {
+    if (one) {
+      constexpr size_t lk = BwdSplitLds<T, DH, DH>::BYTES;
+      size_t lds = lq > lk + reach ? lq : lk + reach;
+      if (lds < (256 + ATT_WAVES) * sizeof(int)) lds = (256 + ATT_WAVES) * sizeof(int);
+      const int64_t per_head = cdiv((int64_t)sh.S_text, ATT_TILE) + cdiv(R, ATT_TILE) + sh.n_slots;
+      auto kernel = branch_attn_bwd_one_kernel<T, DH>;
+      set_lds_limit(kernel, lds);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(per_head * sh.B * sh.H)), dim3(256), lds, st, a);
+      return 2;
+    }
+  }
   const dim3 grid_q((unsigned)cdiv(R, ATT_TILE), (unsigned)(sh.B * sh.H));
   const dim3 grid_k((unsigned)cdiv((int64_t)sh.S_text, ATT_TILE), (unsigned)(sh.B * sh.H));
-  constexpr size_t lq = BwdSplitLds<T, DH, DH>::BYTES;
   auto dqk = branch_attn_bwd_dq_split_kernel<T, DH>;
   set_lds_limit(dqk, lq);
   hipLaunchKernelGGL(dqk, grid_q, dim3(256), lq, st, a);
   if (sh.S_text > 0) {
-    const size_t reach = (size_t)cdiv(R, ATT_TILE) * 4 + 16;
     if constexpr (DH <= 128) {
       launch_dkv_split<T, DH, 0, DH / 32>(a, grid_k, reach, st);
     } else {
@@ -519,27 +597,39 @@ static void launch_split(const AttnArgs& a, hipStream_t st) {
       launch_dkv_split<T, DH, DH / 64, DH / 32>(a, grid_k, reach, st);
     }
   }
+  return 1;
 }
 
-// Launches the dq and dkv work of one backward call in the split form when the shape is covered; false = not covered
-// (fp32 at Dh = 256: four private fp32 tile pairs do not fit the LDS) or switched off (BRANCHGAN_ATTN_BWD_SPLIT=0: A/B runs).
+// Launches the backward in the split form when the shape is covered.  Returns 0 = not covered (fp32 at Dh = 256: four private
+// fp32 tile pairs do not fit the LDS) or switched off (BRANCHGAN_ATTN_BWD_SPLIT=0: A/B runs); 1 = dQ, delta and the text rows'
+// dK / dV are launched, the slot rows are the caller's; 2 = everything is launched (the one-launch form: Dh <= 128, unless
+// BRANCHGAN_ATTN_BWD_ONE=0).
+// The gathers address a (batch, head) slice of q / out / dout with 32-bit element offsets.
+static bool slice_fits_32(const bg_attn_shape& sh) {
+  const int64_t lim = (int64_t)1 << 31;
+  const int64_t q = (int64_t)(sh.NQ - 1) * sh.q_sn + (int64_t)(sh.K - 1) * sh.q_sk + sh.Dh;
+  const int64_t o = (int64_t)(sh.NQ - 1) * sh.o_sn + (int64_t)(sh.K - 1) * sh.o_sk + sh.Dh;
+  return sh.q_sn >= 0 && sh.q_sk >= 0 && sh.o_sn >= 0 && sh.o_sk >= 0 && q < lim && o < lim;
+}
+
 template <typename T>
-bool launch_bwd_split(const AttnArgs& a, hipStream_t st) {
+int launch_bwd_split(const AttnArgs& a, hipStream_t st) {
   static const bool enabled = [] { const char* e = getenv("BRANCHGAN_ATTN_BWD_SPLIT"); return !(e && e[0] == '0'); }();
-  if (!enabled) return false;
+  static const bool one = [] { const char* e = getenv("BRANCHGAN_ATTN_BWD_ONE"); return !(e && e[0] == '0'); }();
+  if (!enabled) return 0;
   const bg_attn_shape& sh = a.sh;
-  if (sizeof(T) == 4 && sh.Dh == 256) return false;
+  if (sizeof(T) == 4 && sh.Dh == 256) return 0;
+  if (!slice_fits_32(sh)) return 0;
   // reach_s lives behind the staging area: one int per query tile
-  if ((size_t)cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * 4 > 16 * 1024) return false;
+  if ((size_t)cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * 4 > 16 * 1024) return 0;
   switch (sh.Dh) {
-    case 32: launch_split<T, 32>(a, st); break;
-    case 64: launch_split<T, 64>(a, st); break;
-    case 128: launch_split<T, 128>(a, st); break;
+    case 32: return launch_split<T, 32>(a, one, st);
+    case 64: return launch_split<T, 64>(a, one, st);
+    case 128: return launch_split<T, 128>(a, one, st);
     default:
-      if constexpr (sizeof(T) == 2) launch_split<T, 256>(a, st);
-      break;
+      if constexpr (sizeof(T) == 2) return launch_split<T, 256>(a, one, st);
+      return 0;
   }
-  return true;
 }
 
 #ifdef BG_ATTN_TRACE
@@ -548,7 +638,7 @@ extern "C" int bg_debug_attn_trace(unsigned long long* host, size_t bytes) {
 }
 #endif
 
-template bool launch_bwd_split<float>(const AttnArgs&, hipStream_t);
-template bool launch_bwd_split<bf16_t>(const AttnArgs&, hipStream_t);
+template int launch_bwd_split<float>(const AttnArgs&, hipStream_t);
+template int launch_bwd_split<bf16_t>(const AttnArgs&, hipStream_t);
 
 }  // namespace bg
