@@ -9,6 +9,8 @@
 // accumulation type ATen's CPU cumsum uses (double accumulate, fp32 compare).  Ties at the cut are resolved in index order.
 // The final pass streams the row once more with the noise: key = (kept ? p : 0) / kept_mass / e, top-n as in topn.hip.
 // One 256-thread workgroup per row; the re-reads of the 200 KB row come from L2 / Infinity Cache, not HBM.
+#include <stdlib.h>
+
 #include "topn_common.h"
 
 namespace bg {
@@ -282,6 +284,23 @@ __global__ __launch_bounds__(256) void topp_kernel(ToppArgs a) {
 // noise once; level 1 is the exponent alone (256 buckets) replicated 16 x by lane so that at most 4 lanes of a wave meet on
 // an address, levels 2 / 3 split the mantissa 12 + 11 bits, and a wave whose active lanes all hit ONE bucket (uniform and
 // near-uniform rows) adds once.  Same arithmetic as the streaming kernel: count + double sum per bucket, fp32 compare.
+// BG_TOPP_TRACE (csrc `make trace`, benchmarks/probes/topp_trace.py): wave 0 of every row's workgroup stamps the wall clock
+// (100 MHz) at the phase boundaries.
+#ifdef BG_TOPP_TRACE
+#define TOPP_TRACE_ROWS 8192
+__device__ unsigned long long g_topp_trace[TOPP_TRACE_ROWS][12];
+#define TOPP_STAMP(slot)                                                                                 \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_waitcnt(0);                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < TOPP_TRACE_ROWS) g_topp_trace[blockIdx.x][slot] = wall_clock64(); \
+  } while (0)
+extern "C" int bg_debug_topp_trace(unsigned long long* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_topp_trace), bytes < sizeof(g_topp_trace) ? bytes : sizeof(g_topp_trace));
+}
+#else
+#define TOPP_STAMP(slot)
+#endif
+
 #define TOPP_NV 13
 #define TOPP_THREADS 1024
 #define TOPP_CAP (TOPP_NV * TOPP_THREADS * 4)
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
   };
 
   // ---- the row, once: vector c of thread t covers elements (c * 512 + t) * 4 - mis + {0..3}; outside [0, V): -1 (skipped) ----
+  TOPP_STAMP(0);
   const int mis = (int)((((uintptr_t)p) & 15) / 4);
   float x[TOPP_NV][4];
 #pragma unroll
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
   };
   auto present = [](unsigned u) { return (int)u >= 0; };          // sign bit = padding
 
+  TOPP_STAMP(1);   // row in registers
   // ---- level 1: exponent (bits 30:23), 16 lane-replicas per bucket -----------------------------------------------------
   clear_hist(4096);
 #pragma unroll
@@ -396,8 +417,10 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
     e_sum[tid] = ss;
   }
   __syncthreads();
+  TOPP_STAMP(2);   // level-1 histogram
   if (wave == 0) scan_sums(e_sum, 256, 0.0, p32, &cross, lane, false);
   __syncthreads();
+  TOPP_STAMP(3);   // level-1 scan
   const bool crossing = cross.found != 0;
   unsigned prefix = 0;
   double cum_gt = cross.cum_before;
@@ -438,8 +461,10 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
           if (v > 0.f && (u >> 23) == b1) atomicAdd(&h_sum[(u >> 11) & 0xFFFu], (double)v);
         }
       __syncthreads();
+      TOPP_STAMP(4);   // min/max + level-2 histogram
       if (wave == 0) scan_sums(h_sum, 4096, cum_gt, p32, &cross, lane, true);
       __syncthreads();
+      TOPP_STAMP(5);   // level-2 scan
       const unsigned pre20 = (b1 << 12) | (unsigned)cross.bucket;
       cum_gt = cross.cum_before;
       __syncthreads();
@@ -454,8 +479,10 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
           if (v > 0.f && (u >> 11) == pre20) atomicAdd(&h_sum[u & 0x7FFu], (double)v);
         }
       __syncthreads();
+      TOPP_STAMP(6);   // level-3 histogram
       if (wave == 0) scan_sums(h_sum, 2048, cum_gt, p32, &cross, lane, true);
       __syncthreads();
+      TOPP_STAMP(7);   // level-3 scan
       cum_gt = cross.cum_before;
       prefix = (pre20 << 11) | (unsigned)cross.bucket;
     }
@@ -570,6 +597,7 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
   const long long idx_cut = sh_idx_cut;
   const float mass = sh_mass;
 
+  TOPP_STAMP(8);   // multiplicity, fit, theta, cut
   // ---- final pass: keys from the registers and the noise (one HBM read), top-n per wave, merge ----------------------------------
   WaveList wl;
   wl.init(n, lane);
@@ -623,9 +651,415 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);     // keep PF noise vectors in flight: hoisting all 13 loads would spill the row
   }
+  TOPP_STAMP(9);   // noise pass + per-wave lists
   if (lane < n) lds_items[wave * n + lane] = wl.item;
   __syncthreads();
   rank_merge_store(lds_items, (TOPP_THREADS / 64) * n, n, a.out_ids + row * n, a.out_keys ? a.out_keys + row * n : nullptr, nullptr);
+  TOPP_STAMP(10);  // merge + store
+}
+
+
+// ---- register-resident variant, second form (round 2) ---------------------------------------------------------------------------
+// The first form above spends 77 us on a row of 50304 (benchmarks/probes/topp_trace.py: 8 us for the row, 8 for the noise -
+// and 60 in between: two 4096- and 2048-bucket scans by ONE wave (9 + 4 us), a third histogram level, three more passes over
+// the registers for the multiplicity of the crossing value and the element above it, and a noise pass that pays two IEEE
+// divisions for every one of the 50304 keys (25 us)).  Here:
+//  * below the exponent the levels are 8 bits wide (256 buckets, count + sum; one wave scans them in under a microsecond) and
+//    stop as soon as the crossing bucket holds at most 64 elements - normally after the first: those are compacted into LDS
+//    and ranked by one wave, which yields the crossing value, its multiplicity, the mass above it AND the next value up;
+//  * the noise pass forms a key only for a kept token that can still enter the wave's list: v >= tau_key * mass * e (with a
+//    relative margin far above the two roundings of (v / mass) / e) is a multiplication and a compare; the divisions run for
+//    the few dozen survivors.  A dropped token's key is +0 unless its noise is 0 or NaN: those rows, rows that keep fewer
+//    than n tokens and rows that keep nothing take the first form's pass (every key formed), so the result is the same.
+// Same arithmetic as before: double sums per bucket, fp32 compare against p, ties at the cut in index order.
+#define TOPP_KEPT_CAP 12288      // kept tokens a row may have on the fast path (96 KB of LDS)
+__global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
+  __shared__ double h_sum[4096];
+  __shared__ unsigned h_cnt[256];
+  __shared__ double e_sum[256];
+  __shared__ unsigned list[64];
+  __shared__ unsigned list_n;
+  __shared__ u64 lds_items[(TOPP_THREADS / 64) * BG_MAX_TOPN];
+  __shared__ Cross cross;
+  __shared__ unsigned red_u[TOPP_THREADS / 64];
+  __shared__ unsigned sh_theta, sh_ntheta, sh_kept, sh_abnormal;
+  __shared__ unsigned l_prefix, l_neq, l_next, l_next_cnt;
+  __shared__ u64 kept_list[TOPP_KEPT_CAP];
+  __shared__ double l_cum;
+  __shared__ long long sh_idx_cut;
+  __shared__ float sh_mass;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const float* p = a.probs + row * a.stride;
+  const float* e = a.noise + row * a.noise_stride;
+  const int V = (int)a.V, n = a.n;
+  const float p32 = a.top_p;
+
+  uint32_t blk[BG_MAX_BLOCKED];
+#pragma unroll
+  for (int i = 0; i < BG_MAX_BLOCKED; ++i) {
+    int64_t b = (i < a.n_blocked) ? a.blocked[row * a.n_blocked + i] : -1;
+    blk[i] = (b >= 0 && b < a.V) ? (uint32_t)b : 0xFFFFFFFFu;
+  }
+  auto value = [&](int i) -> float {                  // global-memory view of element i (rare tie-at-the-cut pass only)
+    float v = p[i];
+    for (int b = 0; b < a.n_blocked; ++b)
+      if (blk[b] == (uint32_t)i) v = 0.f;
+    return v + 0.0f;
+  };
+
+  // ---- the row, once: vector c of thread t covers elements (c * 1024 + t) * 4 - mis + {0..3}; outside [0, V): -1 (skipped) ----
+  TOPP_STAMP(0);
+  const int mis = (int)((((uintptr_t)p) & 15) / 4);
+  float x[TOPP_NV][4];
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    if (i0 >= 0 && i0 + 4 <= V) {
+      const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p + i0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[c][j] = raw[j] + 0.0f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[c][j] = (i0 + j >= 0 && i0 + j < V) ? p[i0 + j] + 0.0f : -1.0f;
+    }
+    for (int b = 0; b < a.n_blocked; ++b) {
+      const uint32_t d = blk[b] - (uint32_t)i0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (d == (uint32_t)j && i0 + j >= 0) x[c][j] = 0.f;
+    }
+  }
+  auto present = [](unsigned u) { return (int)u >= 0; };          // sign bit = padding
+  TOPP_STAMP(1);   // row in registers
+
+  // ---- level 1: exponent (bits 30:23), 16 lane-replicas per bucket, sums only ----------------------------------------------------
+  // The values of one exponent are 24-bit integers times one power of two, so a bucket's sum is an INTEGER sum (below 2^40 for
+  // 53245 elements): exact whatever the order, and a 64-bit integer atomic where a double-precision one was.
+  u64* h_int = (u64*)h_sum;
+  for (int i = tid; i < 4096; i += TOPP_THREADS) h_int[i] = 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = x[c][j];
+      const unsigned u = __float_as_uint(v);
+      const unsigned ex = (u >> 23) & 255u;
+      if (v > 0.f) atomicAdd(&h_int[ex * 16 + (lane & 15)], (u64)((u & 0x7FFFFFu) | (ex ? 0x800000u : 0u)));
+    }
+  __syncthreads();
+  if (tid < 256) {
+    u64 ss = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ss += h_int[tid * 16 + r];
+    e_sum[tid] = ldexp((double)ss, (tid ? tid : 1) - 150);     // exact: ss < 2^53
+  }
+  __syncthreads();
+  TOPP_STAMP(2);   // level-1 histogram
+  if (wave == 0) scan_sums(e_sum, 256, 0.0, p32, &cross, lane, false);
+  __syncthreads();
+  TOPP_STAMP(3);   // level-1 scan
+  const bool crossing = cross.found != 0;
+  unsigned prefix = 0, n_eq = 0, next_up = 0, next_cnt = 0;     // next_up: the value just above the crossing value (0: not known)
+  double cum_gt = cross.cum_before;
+  if (crossing) {
+    prefix = (unsigned)cross.bucket;     // bits 31:23 (sign 0)
+    int shift = 23;
+    unsigned in_bucket = 0xFFFFFFFFu;
+    // ---- deeper levels: 8 + 8 + 7 bits, count and sum, until the crossing bucket is small -------------------------------------
+    for (int lvl = 0; lvl < 3 && in_bucket > 64u; ++lvl) {
+      const int nshift = lvl == 0 ? 15 : (lvl == 1 ? 7 : 0);
+      const unsigned mask = lvl == 2 ? 127u : 255u;
+      if (tid < 256) { h_sum[tid] = 0.0; h_cnt[tid] = 0u; }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = x[c][j];
+          asm volatile("" : "+v"(v));                    // opaque per level: else all 52 (double)v are hoisted out of the level loop (104 registers)
+          const unsigned u = __float_as_uint(v);
+          const bool hit = v > 0.f && (u >> shift) == prefix;
+          const unsigned b = (u >> nshift) & mask;
+          // heavy ties: when many lanes of the wave go to ONE bucket the wave adds once (50k serialised atomics otherwise)
+          const unsigned long long act = __ballot(hit);
+          if (act == 0) continue;
+          const int pc = __popcll(act);
+          bool done = false;
+          if (pc >= 16) {
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, __ffsll(act) - 1);
+            if (__ballot(hit && b != b0) == 0) {
+              // all hits carry values of one bucket; equal bucket at the last level = equal value, else the sum is taken in lane order
+              double s2 = hit ? (double)v : 0.0;
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+              if (lane == 0) { atomicAdd(&h_cnt[b0], (unsigned)pc); atomicAdd(&h_sum[b0], s2); }
+              done = true;
+            }
+          }
+          if (!done && hit) { atomicAdd(&h_cnt[b], 1u); atomicAdd(&h_sum[b], (double)v); }
+        }
+      __syncthreads();
+      if (wave == 0) scan_buckets(h_cnt, h_sum, 256, cum_gt, 0u, p32, &cross, lane, true);
+      __syncthreads();
+      prefix = (prefix << (lvl == 2 ? 7 : 8)) | (unsigned)cross.bucket;
+      shift = nshift;
+      cum_gt = cross.cum_before;
+      in_bucket = h_cnt[cross.bucket];
+      __syncthreads();
+    }
+    TOPP_STAMP(4);   // deeper levels
+    if (shift == 0) {
+      n_eq = in_bucket;                                  // all 31 bits resolved: the bucket is one value
+    } else {
+      // ---- the crossing bucket's elements (at most 64) in LDS, ranked by wave 0 ---------------------------------------------
+      if (tid == 0) list_n = 0;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned u = __float_as_uint(x[c][j]);
+          if (x[c][j] > 0.f && (u >> shift) == prefix) {
+            const unsigned pos = atomicAdd(&list_n, 1u);
+            if (pos < 64u) list[pos] = u;
+          }
+        }
+      __syncthreads();
+      if (wave == 0) {
+        const int cnt = (int)min(list_n, 64u);
+        const unsigned ui = lane < cnt ? list[lane] : 0u;
+        const double vi = (double)__uint_as_float(ui);
+        double gt_sum = 0.0;
+        unsigned eqc = 0;
+        for (int j2 = 0; j2 < cnt; ++j2) {
+          const unsigned uj = list[j2];
+          gt_sum += (uj > ui) ? (double)__uint_as_float(uj) : 0.0;
+          eqc += (uj == ui) ? 1u : 0u;
+        }
+        const bool cr = lane < cnt && (float)(cum_gt + gt_sum + (double)eqc * vi) > p32;
+        unsigned best = cr ? ui : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+        if (best == 0u) {                                // the parent bucket crossed, a last-bit difference of the re-summed
+          best = lane < cnt ? ui : 0xFFFFFFFFu;          // values must not lose it: cross at the smallest value
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        }
+        unsigned nxt = (lane < cnt && ui > best) ? ui : 0xFFFFFFFFu;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, o));
+        const unsigned long long is_best = __ballot(lane < cnt && ui == best);
+        const unsigned long long is_next = __ballot(lane < cnt && ui == nxt);
+        if (lane == __ffsll(is_best) - 1) {
+          l_prefix = ui; l_neq = eqc; l_cum = cum_gt + gt_sum;
+          l_next = nxt == 0xFFFFFFFFu ? 0u : nxt;
+          l_next_cnt = (unsigned)__popcll(is_next);
+        }
+      }
+      __syncthreads();
+      prefix = l_prefix; n_eq = l_neq; cum_gt = l_cum; next_up = l_next; next_cnt = l_next_cnt;
+    }
+  }
+  TOPP_STAMP(5);   // list stage
+
+  // ---- how many copies of the crossing value tau still fit (sequential double adds of tau in the reference) -------------
+  unsigned c_fit = 0;
+  const double tau = crossing ? (double)__uint_as_float(prefix) : 0.0;
+  if (crossing) {
+    if (tau == 0.0) c_fit = n_eq;
+    else {
+      double guess = floor(((double)p32 - cum_gt) / tau);
+      long long c0 = guess < 0 ? 0 : (guess > (double)n_eq ? (long long)n_eq : (long long)guess);
+      while (c0 < (long long)n_eq && (float)(cum_gt + (double)(c0 + 1) * tau) <= p32) ++c0;
+      while (c0 > 0 && (float)(cum_gt + (double)c0 * tau) > p32) --c0;
+      c_fit = (unsigned)c0;
+    }
+  }
+  unsigned theta, r, n_theta;
+  double e_star;
+  bool none_kept = false;
+  if (crossing && c_fit >= 1) {
+    theta = prefix; r = c_fit - 1; n_theta = n_eq; e_star = tau;
+  } else if (crossing && next_up != 0u) {                // e* = the worst-ranked element above tau: the list knows it
+    theta = next_up; n_theta = next_cnt; r = n_theta - 1; e_star = (double)__uint_as_float(theta);
+  } else {
+    // smallest value above tau (of the whole row when nothing crossed), then how often it occurs.  (One pass that carries
+    // (min, count) pairs through the lanes was slower: 16 waves share the CU's 64 lanes, every instruction per element is 0.35 us.)
+    const unsigned lo = crossing ? prefix : 0u;
+    unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u = __float_as_uint(x[c][j]);
+        if (present(u) && (!crossing || u > lo) && u < mn) mn = u;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+    if (lane == 0) red_u[wave] = mn;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned m2 = red_u[0];
+      for (int w = 1; w < TOPP_THREADS / 64; ++w) m2 = min(m2, red_u[w]);
+      sh_theta = m2;
+    }
+    __syncthreads();
+    theta = sh_theta;
+    if (theta == 0xFFFFFFFFu) { none_kept = true; r = 0; n_theta = 0; e_star = 0.0; }
+    else {
+      unsigned cc = 0;
+#pragma unroll
+      for (int c = 0; c < TOPP_NV; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cc += (__float_as_uint(x[c][j]) == theta) ? 1u : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor((int)cc, o);
+      __syncthreads();
+      if (lane == 0) red_u[wave] = cc;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned t2 = 0;
+        for (int w = 0; w < TOPP_THREADS / 64; ++w) t2 += red_u[w];
+        sh_ntheta = t2;
+      }
+      __syncthreads();
+      n_theta = sh_ntheta;
+      r = n_theta - 1;
+      e_star = (double)__uint_as_float(theta);
+    }
+  }
+  const double fit_mass = cum_gt + (double)c_fit * tau;
+  if (tid == 0) {
+    sh_mass = none_kept ? 0.0f : (float)(fit_mass - e_star);
+    sh_idx_cut = (r == 0) ? -1 : (long long)V;
+    sh_kept = 0u;
+    sh_abnormal = 0u;
+  }
+  __syncthreads();
+  if (!none_kept && r > 0 && r < n_theta && wave == 0) {     // ties at the cut: the r-th theta-valued element in index order
+    unsigned running = 0;
+    long long cut = V;
+    for (int base = 0; base < V; base += 64) {
+      const int i = base + lane;
+      const bool eq = (i < V) && (__float_as_uint(value(i)) == theta);
+      const unsigned long long bal = __ballot(eq);
+      const unsigned c = (unsigned)__popcll(bal);
+      if (running + c >= r) {
+        unsigned need = r - running;
+        unsigned long long m = bal;
+        for (unsigned k = 1; k < need; ++k) m &= m - 1;
+        cut = base + (__ffsll(m) - 1);
+        break;
+      }
+      running += c;
+    }
+    if (lane == 0) sh_idx_cut = cut;
+  }
+  __syncthreads();
+  const int idx_cut = (int)sh_idx_cut;                 // -1 .. V: fits
+  const float mass = sh_mass;
+  TOPP_STAMP(8);   // fit, theta, cut
+
+  // ---- the kept tokens, compacted: (value bits, index) pairs in LDS.  After this the row's registers are free. ---------------
+  if (!none_kept) {
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c) {
+      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned u = __float_as_uint(x[c][j]);
+        const bool kept = present(u) & ((u > theta) | ((u == theta) & (i0 + j <= idx_cut)));
+        const unsigned long long bal = __ballot(kept);
+        if (bal == 0) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&sh_kept, (unsigned)__popcll(bal));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (kept && pos < TOPP_KEPT_CAP) kept_list[pos] = ((u64)(uint32_t)(i0 + j) << 32) | u;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned K = sh_kept;
+  TOPP_STAMP(9);   // kept list
+  // The fast pass needs at least n kept tokens (else the zero keys of dropped tokens fill the list, in index order), a list
+  // that fits, a finite positive mass - and noise without zeros or NaNs: a dropped token's key is (+0 / mass) / e = +0 unless e
+  // is 0 or NaN, then it is NaN and sorts first.  The whole noise row is read once to see that; the keys come from the list.
+  bool slow = none_kept || K < (unsigned)n || K > TOPP_KEPT_CAP || !(mass > 0.f) || !(mass < INFINITY);
+  WaveList wl;
+  wl.init(n, lane);
+  const char* e_al = (const char*)(e - mis);           // the probabilities' misalignment (checked on the host): aligned vectors
+  if (!slow) {
+    f32x4 en[TOPP_NV];
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c) {
+      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+      en[c] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+      // a vector that straddles the row's ends is read whole: the bytes outside belong to the neighbouring rows or to the
+      // 16-byte block the row ends in; its outside elements are ignored below
+      if (i0 > -4 && i0 < V) en[c] = __builtin_nontemporal_load((const f32x4*)(e_al + (unsigned)((c * TOPP_THREADS + tid) * 16)));
+    }
+    // keys of the kept tokens while the row is in flight: thread t takes entries t, t + 1024, ...
+    for (unsigned t0 = 0; t0 < K; t0 += TOPP_THREADS) {
+      const unsigned t = t0 + tid;
+      u64 mine = 0;
+      if (t < K) {
+        const u64 ent = kept_list[t];
+        const uint32_t idx = (uint32_t)(ent >> 32);
+        const float v = __uint_as_float((uint32_t)ent);
+        const u64 it = make_item((v / mass) / e[idx], idx);
+        mine = it > wl.tau ? it : 0;
+      }
+      wl.offer_lanes(mine);
+    }
+    bool abnormal = false;
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c) {
+      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) abnormal |= (i0 + j >= 0) & (i0 + j < V) & !(fabsf(en[c][j]) > 0.f);
+    }
+    if (__ballot(abnormal) != 0 && lane == 0) atomicOr(&sh_abnormal, 1u);
+    __syncthreads();
+    slow = sh_abnormal != 0u;
+  }
+  if (slow) {
+    // every key formed, row and noise read again a vector at a time: rows that keep fewer than n tokens are filled from the zero
+    // keys in index order, rows that keep nothing are all NaN, and a zero or NaN noise value makes a dropped token's key NaN
+    wl.init(n, lane);
+    const float zero_over_mass = 0.f / mass;               // +0, or NaN when nothing is kept
+    for (int c = 0; c < TOPP_NV; ++c) {
+      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+      u64 it[4];
+      uint32_t cmask = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = i0 + j >= 0 && i0 + j < V;
+        const float v = in ? value(i0 + j) : -1.0f;
+        const float ej = in ? e[i0 + j] : 1.0f;
+        const unsigned u = __float_as_uint(v);
+        const bool kept = !none_kept && (u > theta || (u == theta && (i0 + j) <= idx_cut));
+        const float key = kept ? (v / mass) / ej : zero_over_mass / ej;
+        it[j] = make_item(key, (uint32_t)(i0 + j));
+        cmask |= (in && it[j] > wl.tau) ? (1u << j) : 0u;
+      }
+      while (__ballot(cmask != 0)) {
+        u64 mine = 0;
+        if (cmask) {
+          const int j = __ffs(cmask) - 1;
+          cmask &= cmask - 1;
+          mine = j == 0 ? it[0] : (j == 1 ? it[1] : (j == 2 ? it[2] : it[3]));
+        }
+        wl.offer_lanes(mine);
+      }
+    }
+  }
+  if (lane < n) lds_items[wave * n + lane] = wl.item;
+  __syncthreads();
+  rank_merge_store(lds_items, (TOPP_THREADS / 64) * n, n, a.out_ids + row * n, a.out_keys ? a.out_keys + row * n : nullptr, nullptr);
+  TOPP_STAMP(10);  // merge + store
 }
 
 }  // namespace bg
@@ -648,7 +1082,11 @@ extern "C" int bg_topp_select(const float* probs, int64_t rows, int64_t V, int64
   BG_REQUIRE(n_blocked >= 0 && n_blocked <= BG_MAX_BLOCKED && (n_blocked == 0 || blocked), "bg_topp_select: n_blocked=%d", n_blocked);
   BG_REQUIRE(top_p == top_p, "bg_topp_select: top_p is NaN");
   ToppArgs a{probs, noise, blocked, V, row_stride, noise_row_stride, n, n_blocked, top_p, out_ids, out_keys};
-  if (V + 3 <= TOPP_CAP) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
+  static const bool first_form = [] { const char* e = getenv("BRANCHGAN_TOPP_FIRST_FORM"); return e && e[0] == '1'; }();   // A/B runs
+  if (V + 3 <= TOPP_CAP && first_form) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
+  else if (V + 3 <= TOPP_CAP && ((uintptr_t)noise - (uintptr_t)probs) % 16 == 0 && ((noise_row_stride - row_stride) * 4) % 16 == 0)
+    hipLaunchKernelGGL(topp_fast_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
+  else if (V + 3 <= TOPP_CAP) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(topp_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
   BG_CHECK_LAUNCH("bg_topp_select");
   return BG_OK;
