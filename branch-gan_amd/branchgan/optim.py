@@ -112,17 +112,43 @@ class ArenaAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.steps += 1
         lp = self.lowp_arena
+        ga = self.grad_arena
+        lo, hi = ga.shard_range()
+        sharded = ga.sharded_active()
+        if sharded and ga.shard is None:
+            raise RuntimeError("ArenaAdam: sharded step before the gradients were reduce-scattered (OptimizerWrapper.backward does it)")
+        grads = ga.shard if sharded else ga.arena          # the reduce-scatter left this rank's summed slice in ga.shard
         if self.timing is not None:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-        C.check(C.lib().bg_adam_step(C.ptr(self.param_arena), C.ptr(self.grad_arena.arena), C.ptr(self.exp_avg), C.ptr(self.exp_avg_sq),
-                                     C.ptr(lp), C.dtype_code(lp) if lp is not None else 0, self.param_arena.numel(),
+        C.check(C.lib().bg_adam_step(C.ptr(self.param_arena[lo:hi]), C.ptr(grads), C.ptr(self.exp_avg[lo:hi]), C.ptr(self.exp_avg_sq[lo:hi]),
+                                     C.ptr(lp) if lp is not None and not sharded else None, C.dtype_code(lp) if lp is not None else 0, hi - lo,
                                      float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                      float(g['weight_decay']), self.steps, float(self.grad_scale), 1, C.stream_ptr()), "bg_adam_step")
         if self.timing is not None:
             t1.record()
             self.timing.append((t0, t1))
+        if sharded:
+            # every rank gets every slice of the fp32 parameters; the low-precision copies are re-rounded here (6 B per parameter
+            # of HBM traffic against 2 B per parameter over the links) and the local gradients, consumed by nobody, are cleared
+            from .training import all_gather_slices
+            all_gather_slices(self.param_arena, self.param_arena[lo:hi].clone(), ga.group)
+            if lp is not None:
+                lp.copy_(self.param_arena)
+            ga.arena.zero_()
+            self._moments_gathered = False
         return loss
+
+    def gather_state(self):
+        """Sharded data parallelism: a collective that gives every rank the whole Adam moments (before state_dict / a save).
+        Nothing to do otherwise."""
+        if self.param_arena is None or self.grad_arena is None or getattr(self, "_moments_gathered", True):
+            return
+        from .training import all_gather_slices
+        lo, hi = self.grad_arena.shard_range()
+        for t in (self.exp_avg, self.exp_avg_sq):
+            all_gather_slices(t, t[lo:hi].clone(), self.grad_arena.group)
+        self._moments_gathered = True
 
     def zero_grad(self, set_to_none=False):
         if self.grad_arena is not None and self.grad_arena.arena is not None:
@@ -132,6 +158,9 @@ class ArenaAdam(torch.optim.Optimizer):
 
     # torch.optim.Adam's state layout, so checkpoints move between the two ------------------------------------------------
     def state_dict(self):
+        if not getattr(self, "_moments_gathered", True):
+            raise RuntimeError("ArenaAdam.state_dict under BRANCHGAN_DP_SHARDED=1: call gather_state() on every rank first "
+                               "(each rank holds the moments of its own slice only)")
         if self.param_arena is not None:
             step = torch.tensor(float(self.steps))
             for p, off in zip(self.grad_arena.params, self.grad_arena.offsets):

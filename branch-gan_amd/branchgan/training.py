@@ -10,6 +10,7 @@ point-to-point: fewer, larger collectives) on a side stream, overlapping the gen
 backward.  Parameters that never receive a gradient (generator valueHead, discriminator LM head) are left out of the arena.
 Mathematically identical to the reference's averaging (sum / world).
 """
+import contextlib
 import os
 
 import torch
@@ -69,15 +70,80 @@ def init_data_parallel(backend=None):
     return rank, world, local
 
 
-class GradArena:
-    """Flat gradient storage of one model + bucketed all-reduce(sum)/world over the process group."""
+# BRANCHGAN_DP_SHARDED=1: instead of all-reducing the gradient arena and stepping every parameter on every rank, reduce-scatter it
+# (rank r gets the sum of slice r), let optim.ArenaAdam step slice r only - 1/world of the optimizer's 34 B per parameter - and
+# all-gather the fp32 parameters.  Same bytes on the links (reduce-scatter + all-gather = one ring all-reduce), same result bit
+# for bit (the kernel is element-wise), the update's HBM time divided by the world size.
+DP_SHARDED = os.environ.get("BRANCHGAN_DP_SHARDED") == "1"
 
-    def __init__(self, module, bucket_bytes=64 << 20, group=None):
+
+class _Done:
+    def wait(self):
+        pass
+
+
+def _through_host(t, group):
+    """gloo with GPU tensors (several ranks rehearsing on ONE GPU: tests/test_gpu_dp.py) goes through host copies made HERE:
+    gloo's own device path stalls for good on transfers of a few MB between two processes that share a device
+    (benchmarks/probes/gloo_cuda_collectives.py: 12 all-gathers of 1 MB pass, the first of 4 MB never returns)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None, async_op=True):
+    if _through_host(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) or _Done()
+
+
+def reduce_scatter_sum(out, inp, group=None, async_op=True):
+    if _through_host(inp, group):
+        h, o = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(o, h, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(o)
+        return _Done()
+    return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op) or _Done()
+
+
+def all_gather_slices(full, mine, group=None):
+    """full = the ranks' `mine` slices one after the other (blocking)."""
+    if _through_host(full, group):
+        o = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(o, mine.cpu(), group=group)
+        full.copy_(o)
+        return
+    dist.all_gather_into_tensor(full, mine, group=group)
+
+
+class GradArena:
+    """Flat gradient storage of one model + bucketed all-reduce(sum)/world over the process group (or, sharded, one
+    reduce-scatter)."""
+
+    def __init__(self, module, bucket_bytes=64 << 20, group=None, sharded=None):
         self.module, self.bucket_bytes, self.group = module, bucket_bytes, group
         self.arena = None
         self.params, self.offsets = [], []
         self.stream = None
         self._work = []
+        self.sharded = DP_SHARDED if sharded is None else sharded
+        self.shard = None            # (sharded, world > 1) this rank's slice of the summed gradients, filled by reduce_async
+
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def sharded_active(self):
+        """Sharded AND more than one rank (or the one-rank RCCL rehearsal, which runs the same collectives with world 1)."""
+        return self.sharded and dist.is_initialized() and (self.world() > 1 or REHEARSE_RCCL)
+
+    def shard_range(self):
+        """[lo, hi) of the arena this rank steps; the whole arena unless sharded over more than one rank."""
+        n, w = self.arena.numel(), self.world()
+        if not self.sharded_active():
+            return 0, n
+        r = dist.get_rank(self.group)
+        return r * (n // w), (r + 1) * (n // w)
 
     def _build(self):
         self.params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
@@ -85,6 +151,9 @@ class GradArena:
         for p in self.params:                 # every parameter starts on a 32-byte boundary (16-byte vectors in fp32 and bf16)
             self.offsets.append(n)
             n += (p.numel() + 7) & ~7
+        if self.sharded:                      # equal slices that start on 32-byte boundaries
+            step = 8 * self.world()
+            n = (n + step - 1) // step * step
         dev = self.params[0].device
         self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, off in zip(self.params, self.offsets):
@@ -112,6 +181,17 @@ class GradArena:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1 and not (REHEARSE_RCCL and dist.is_initialized()):
             return
+        if self.sharded_active():
+            lo, hi = self.shard_range()
+            if self.shard is None:
+                self.shard = torch.zeros(hi - lo, dtype=torch.float32, device=self.arena.device)
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream())
+            with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+                if average:
+                    self.arena.div_(world)
+                self._work.append(reduce_scatter_sum(self.shard, self.arena, self.group))
+            return
         per = max(1, self.bucket_bytes // 4)
         buckets = [self.arena[i:i + per] for i in range(0, self.arena.numel(), per)]
         if self.stream is not None:
@@ -120,12 +200,12 @@ class GradArena:
                 for b in buckets:
                     if average:
                         b.div_(world)
-                    self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._work.append(all_reduce_sum(b, self.group))
         else:
             for b in buckets:
                 if average:
                     b.div_(world)
-                self._work.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._work.append(all_reduce_sum(b, self.group))
 
     def wait(self):
         for w in self._work:
@@ -144,6 +224,9 @@ class OptimizerWrapper:
         self.arena = arena if arena is not None else GradArena(model)
         if hasattr(optimizer, "bind"):             # optim.ArenaAdam lays its own arenas out next to the gradient arena
             optimizer.bind(self.arena)
+        elif self.arena.sharded and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ValueError("BRANCHGAN_DP_SHARDED=1 needs the arena optimizer (make_optimizer(..., 'adam') on the GPU): "
+                             f"{type(optimizer).__name__} steps whole parameters")
 
     def reduce_async(self):
         """Starts the gradient all-reduce of an optimizer step.  The mean over ranks is either taken here or, for an
@@ -321,7 +404,8 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
     (torch.bfloat16 or None) is the autocast dtype of those steps."""
     from . import checkpoint, schedules
     sched = genDiscUpdateSchedule if genDiscUpdateSchedule is not None else schedules.AlwaysUpdateSchedule()
-    tracker = schedules.ModelSaveFrequencyTracker(kwargs.pop('saveFreq', None), len(trainDataset), enabled=saveModel,
+    # the save points are worked out on EVERY rank (gather_state is a collective); only ranks with saveModel write
+    tracker = schedules.ModelSaveFrequencyTracker(kwargs.pop('saveFreq', None), len(trainDataset), enabled=saveModel or DP_SHARDED,
                                                   epochSaveFrequency=kwargs.pop('epochSaveFreq', None))
     save_root, sink = kwargs.pop('mainSavePath', ''), kwargs.pop('logSink', print)
     use_graphs, amp_dtype, graphed = kwargs.pop('useGraphs', False), kwargs.pop('ampDtype', None), {}
@@ -336,6 +420,11 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
             gs.join()
     depthSchedule = getattr(trainingConf, 'depthSchedule', None)
     rlConf = getattr(trainingConf, 'reinforcementLearningConfig', None)
+
+    def gather_state():
+        for o in (generatorOptim, discriminatorOptim):          # sharded data parallelism: every rank holds a slice of the moments
+            if hasattr(o.optimizer, "gather_state"):
+                o.optimizer.gather_state()
 
     def save(marker):
         checkpoint.saveGannSetup(model, saveName, marker, discriminatorOptim, generatorOptim, mainSavePath=save_root, datasetConf=datasetConf,
@@ -376,14 +465,19 @@ def efficentTrainingLoop(model, trainDataset, testData, numEpochs, generatorOpti
                     log.extend(logResults(validationResult, genData, discData, trainDataset, epochCounter, i, generatorOptim, discriminatorOptim,
                                           trainingConf, sink=sink))
                 discData, genData = {}, {}
+                gather_state()
                 if saveModel:
                     save('Current')
             due, name = tracker.shouldModelBeSaved(i, epochCounter)
-            if saveModel and due:
+            if due:
                 join_graphs()
-                save(name)
+                gather_state()
+                if saveModel:
+                    save(name)
         epochCounter += 1
         join_graphs()
-        if saveModel and tracker.epochSaveFrequency and tracker.shouldModelBeSavedAtThisEpoch(epochCounter):
-            save("Epoch-{}".format(epochCounter))
+        if tracker.epochSaveFrequency and tracker.shouldModelBeSavedAtThisEpoch(epochCounter):
+            gather_state()
+            if saveModel:
+                save("Epoch-{}".format(epochCounter))
     return log

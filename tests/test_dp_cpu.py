@@ -46,6 +46,44 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _sharded_worker(rank, world, port, tmp):
+    """BRANCHGAN_DP_SHARDED's collective half on the CPU: reduce-scatter of the padded arena = this rank's slice of the all-reduce."""
+    sys.path.insert(0, os.path.join(ROOT, "branch-gan_amd"))
+    from branchgan import training
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    training.init_data_parallel("gloo")
+    torch.manual_seed(0)
+    model = Tiny()
+    data, target = torch.randn(8, 6), torch.randn(8)
+    ((model(data[rank * 4:rank * 4 + 4]) - target[rank * 4:rank * 4 + 4]) ** 2).mean().backward()
+    arena = training.GradArena(model, sharded=True)
+    arena._build()
+    assert arena.arena.numel() % (8 * world) == 0 and arena.sharded_active()
+    want = arena.arena.clone()
+    dist.all_reduce(want)
+    arena.reduce_async(average=False)
+    arena.wait()
+    lo, hi = arena.shard_range()
+    assert (lo, hi) == (rank * arena.arena.numel() // world, (rank + 1) * arena.arena.numel() // world)
+    assert torch.equal(arena.shard, want[lo:hi]) and bool(arena.shard.any() or rank == 1)
+    full = torch.zeros_like(want)
+    training.all_gather_slices(full, arena.shard)
+    assert torch.equal(full, want)
+    try:
+        training.OptimizerWrapper(model, training.make_optimizer(model.parameters(), "sgd", 0.1), arena=arena)
+        raise AssertionError("a whole-parameter optimizer must be refused under sharding")
+    except ValueError as e:
+        assert "BRANCHGAN_DP_SHARDED" in str(e)
+    dist.destroy_process_group()
+
+
+def test_sharded_reduce_scatter_and_all_gather_on_gloo(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
 def test_two_rank_gloo_matches_single_process(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
