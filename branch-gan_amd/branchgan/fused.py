@@ -446,6 +446,108 @@ def _accumulate_matmul(p, a, b):
     return ret
 
 
+# Weight gradients, batched.  A transformer's backward pass issues one dW GEMM per weight and pass - at BASELINE configs[1]
+# 768 x 768 .. 768 x 3072 outputs over 2048 rows: 36 - 144 tiles for 256 CUs, ~20 us each, 3.9 ms of a 19 ms step
+# (profiles/r1_n_bench_c2_by_class.txt).  Nothing inside the pass reads a weight gradient, so the GEMMs wait: when the pass ends
+# (the autograd-engine callback the column reductions use) the waiting products are grouped - same shapes, same layout, gradient
+# buffers at one constant stride (the layers of one weight kind in the flat arena) - and each group runs as ONE strided-batched
+# GEMM straight into the arena, the passes that share a weight (root and tree pass) concatenated along the reduction dimension.
+# What cannot be grouped runs as before, just later.  BRANCHGAN_BATCH_DW=0: every dW GEMM where it arises.
+BATCH_DW = os.environ.get("BRANCHGAN_BATCH_DW", "1") != "0"
+
+
+class _DeferredWeightGrads:
+    def __init__(self, device):
+        self.device = device
+        self.pending, self.armed, self.task = [], False, -1
+        self.streams = set()
+
+    def begin(self):
+        task = torch._C._current_graph_task_id()
+        if task < 0:
+            return False
+        if self.armed and self.task == task:
+            return True
+        if self.pending:
+            self.flush()
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        except RuntimeError:
+            self.armed = False
+            return False
+        self.armed, self.task = True, task
+        return True
+
+    def add(self, weight, buf, layout, x2, dy2):
+        self.pending.append((weight, buf, layout, x2, dy2))
+        self.streams.add(torch.cuda.current_stream(self.device))
+
+    def flush(self):
+        self.armed = False
+        pending, self.pending = self.pending, []
+        streams, self.streams = self.streams, set()
+        if not pending:
+            return
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            for st in streams:
+                if st != cur:
+                    cur.wait_stream(st)
+            per_weight = {}
+            for weight, buf, layout, x2, dy2 in pending:
+                per_weight.setdefault(id(weight), (buf, layout, [], []))
+                per_weight[id(weight)][2].append(x2)
+                per_weight[id(weight)][3].append(dy2)
+            groups = {}
+            for buf, layout, xs, dys in per_weight.values():
+                key = (layout, xs[0].dtype, tuple(buf.shape), tuple(x.shape[0] for x in xs), xs[0].shape[1], dys[0].shape[1])
+                groups.setdefault(key, []).append((buf, xs, dys))
+            for (layout, dtype, wshape, rows, n_in, n_out), members in groups.items():
+                members.sort(key=lambda m: m[0].data_ptr())
+                stride = None
+                if len(members) > 1 and dtype != torch.float32 and _mm_out_dtype:
+                    d = [(b[0].data_ptr() - members[0][0].data_ptr()) for b in members]
+                    step = d[1]
+                    if step % 4 == 0 and step // 4 >= members[0][0].numel() and all(x == i * step for i, x in enumerate(d)) \
+                            and all(m[0].is_contiguous() for m in members) \
+                            and all(m[0].untyped_storage().data_ptr() == members[0][0].untyped_storage().data_ptr() for m in members):
+                        stride = step // 4
+                if stride is None:
+                    for buf, xs, dys in members:
+                        for x2, dy2 in zip(xs, dys):
+                            _accumulate_into(buf, x2.t(), dy2) if layout == "io" else _accumulate_into(buf, dy2.t(), x2)
+                    continue
+                L, R = len(members), sum(rows)
+                xa = torch.empty((L, R, n_in), dtype=dtype, device=self.device)
+                da = torch.empty((L, R, n_out), dtype=dtype, device=self.device)
+                torch.cat([x for _, xs, _ in members for x in xs], out=xa.view(L * R, n_in))
+                torch.cat([d_ for _, _, dys in members for d_ in dys], out=da.view(L * R, n_out))
+                out = members[0][0].as_strided((L,) + wshape, (stride, wshape[1], 1))
+                if layout == "io":
+                    torch.baddbmm(out, xa.transpose(1, 2), da, out_dtype=torch.float32, out=out)
+                else:
+                    torch.baddbmm(out, da.transpose(1, 2), xa, out_dtype=torch.float32, out=out)
+
+
+_deferred_dw = {}
+
+
+def _deferred_dw_for(device):
+    d = _deferred_dw.get(device)
+    if d is None:
+        d = _deferred_dw[device] = _DeferredWeightGrads(device)
+    return d
+
+
+def _accumulate_into(buf, a, b):
+    if a.dtype == torch.float32:
+        buf.addmm_(a, b)
+    elif _mm_out_dtype or (_mm_out_dtype is None and not torch.cuda.is_current_stream_capturing() and _probe_mm_out_dtype(a.device)):
+        torch.addmm(buf, a, b, out_dtype=torch.float32, out=buf)
+    else:
+        buf.add_(torch.mm(a, b))
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x @ W + b).  layout 'io': W is (in, out) (GPT-2 Conv1D); 'oi': (out, in) (nn.Linear)."""
 
@@ -503,7 +605,21 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, w.t() if layout == "io" else w).view(in_shape)
-        dw_ret = _accumulate_matmul(weight, x2.t(), dy2) if layout == "io" else _accumulate_matmul(weight, dy2.t(), x2)
+        dw_ret = None
+        later = None
+        if BATCH_DW and weight.requires_grad:
+            buf, ret = _grad_buffer(weight)
+            if ret is None:                              # the gradient lives in p.grad (the arena): the GEMM can wait
+                later = _deferred_dw_for(dy2.device)
+                if later.begin():
+                    later.add(weight, buf, layout, x2, dy2)
+                else:
+                    later = None
+            if later is None:
+                _accumulate_into(buf, x2.t(), dy2) if layout == "io" else _accumulate_into(buf, dy2.t(), x2)
+                dw_ret = ret
+        else:
+            dw_ret = _accumulate_matmul(weight, x2.t(), dy2) if layout == "io" else _accumulate_matmul(weight, dy2.t(), x2)
         return dx, dw_ret, db_ret, None, None, None, None
 
 
