@@ -344,6 +344,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 timing of the same workload")
+    ap.add_argument("--no-rooflines", action="store_true", help="timed steps only: no replay of the attention launch mix (a clean kernel trace under rocprofv3)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="hipBLASLt default heuristics instead of the recorded TunableOp choices")
     args = ap.parse_args()
@@ -417,7 +418,7 @@ def main():
         return elapsed, losses, roofs
 
     main_dtype = "bf16" if args.dtype == "bf16" else "f32"
-    elapsed, losses, roofs = run(main_dtype, args.steps, args.warmup, True)
+    elapsed, losses, roofs = run(main_dtype, args.steps, args.warmup, not args.no_rooflines)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -8,13 +8,14 @@ import sys
 def klass(n):
     if n.startswith('Cijk') or n.startswith('Custom_Cijk') or 'gemm' in n.lower(): return 'gemm (hipBLASLt)'
     if '_ZN2bg' in n or 'bg::' in n:
-        for k in ('adam_step', 'embed_', 'attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_slots', 'attn_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'bias_act_bwd',
+        for k in ('adam_step', 'embed_', 'attn_bwd_one', 'attn_bwd_dq', 'attn_bwd_dkv', 'attn_bwd_slots', 'attn_fwd', 'attn_weights', 'layernorm_bwd', 'add_layernorm_fwd', 'bias_act_bwd',
                   'partial_reduce', 'softmax_stats', 'topn', 'topp', 'loss', 'rope'):
             if k in n: return 'bg:' + k
         return 'bg:other'
     if 'layer_norm' in n or 'GammaBeta' in n: return 'torch layernorm'
     if 'multi_tensor' in n or 'FusedAdam' in n or 'fused_adam' in n.lower(): return 'torch adam/foreach'
     if 'reduce_kernel' in n: return 'torch reduce'
+    if 'CatArrayBatchedCopy' in n: return 'torch cat (dW operand stacking)'
     if 'copy' in n.lower(): return 'torch copy/cast'
     if 'Fill' in n or 'fillBuffer' in n: return 'torch fill'
     if 'CUDAFunctor_add' in n or 'AddFunctor' in n: return 'torch add'

@@ -43,6 +43,10 @@ class ReduceDesc(ctypes.Structure):
     _fields_ = [("partial", c_vp), ("out", c_vp), ("groups", c_i32), ("stride", c_i32), ("n", c_i32), ("reserved", c_i32)]
 
 
+class StackDesc(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("rows", c_i64), ("row_bytes", c_i64), ("src_row_stride", c_i64)]
+
+
 # name -> (restype, argtypes); every symbol include/branchgan.h declares
 SIGNATURES = {
     "bg_last_error": (ctypes.c_char_p, []),
@@ -74,6 +78,7 @@ SIGNATURES = {
     "bg_layernorm_bwd_groups": (c_i32, [c_i64]),
     "bg_bias_act_bwd_groups": (c_i32, [c_i64]),
     "bg_partial_reduce": (c_i32, [ctypes.POINTER(ReduceDesc), c_i32, c_vp]),
+    "bg_stack_rows": (c_i32, [ctypes.POINTER(StackDesc), c_i32, c_vp]),
     "bg_bias_act_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_bias_act_bwd": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_embed_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp]),

@@ -520,13 +520,35 @@ class _DeferredWeightGrads:
                 L, R = len(members), sum(rows)
                 xa = torch.empty((L, R, n_in), dtype=dtype, device=self.device)
                 da = torch.empty((L, R, n_out), dtype=dtype, device=self.device)
-                torch.cat([x for _, xs, _ in members for x in xs], out=xa.view(L * R, n_in))
-                torch.cat([d_ for _, _, dys in members for d_ in dys], out=da.view(L * R, n_out))
+                _stack_rows([x for _, xs, _ in members for x in xs], xa.view(L * R, n_in),
+                            [d_ for _, _, dys in members for d_ in dys], da.view(L * R, n_out))
                 out = members[0][0].as_strided((L,) + wshape, (stride, wshape[1], 1))
                 if layout == "io":
                     torch.baddbmm(out, xa.transpose(1, 2), da, out_dtype=torch.float32, out=out)
                 else:
                     torch.baddbmm(out, da.transpose(1, 2), xa, out_dtype=torch.float32, out=out)
+
+
+def _stack_rows(xs, xa, dys, da):
+    """xa = the xs one under the other, da = the dys: ONE bg_stack_rows launch (torch.cat when a source is not 16-byte regular)."""
+    descs, ok = [], True
+    for srcs, dst in ((xs, xa), (dys, da)):
+        row_bytes, off = dst.shape[1] * dst.element_size(), 0
+        for t in srcs:
+            es = t.element_size()
+            if t.stride(1) != 1 or row_bytes % 16 or (t.stride(0) * es) % 16 or t.data_ptr() % 16 or (dst.data_ptr() + off) % 16:
+                ok = False
+            descs.append((t.data_ptr(), dst.data_ptr() + off, t.shape[0], row_bytes, t.stride(0) * es))
+            off += t.shape[0] * row_bytes
+    if not ok:
+        torch.cat(xs, out=xa)
+        torch.cat(dys, out=da)
+        return
+    arr = (C.StackDesc * len(descs))()
+    for d, (src, dst, rows, rb, st) in zip(arr, descs):
+        d.src, d.dst, d.rows, d.row_bytes, d.src_row_stride = src, dst, rows, rb, st
+    with ops._timed("stack_rows"):
+        C.check(C.lib().bg_stack_rows(arr, len(descs), C.stream_ptr()), "bg_stack_rows")
 
 
 _deferred_dw = {}

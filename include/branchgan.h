@@ -248,6 +248,16 @@ typedef struct bg_reduce_desc {
   int32_t groups, stride, n, reserved;
 } bg_reduce_desc;
 int bg_partial_reduce(const bg_reduce_desc* descs, int count, void* stream);
+/* Row-block gather for the batched weight-gradient GEMMs (no counterpart in the reference, whose autograd issues one dW GEMM per
+ * nn.Linear / Conv1D: Models/GPT2BranchAttention/GPT2NonResidualAttention.py:75-80 c_attn / c_proj, transformers' GPT2MLP): every
+ * descriptor copies `rows` rows of `row_bytes` bytes, `src_row_stride` bytes apart, to the contiguous `dst`; all of them in
+ * launches of up to 48 descriptors.  Rows, strides and pointers are multiples of 16 bytes. */
+typedef struct bg_stack_desc {
+  const void* src;
+  void* dst;
+  int64_t rows, row_bytes, src_row_stride;
+} bg_stack_desc;
+int bg_stack_rows(const bg_stack_desc* descs, int count, void* stream);
 int bg_layernorm_bwd_groups(int64_t rows);
 int bg_bias_act_bwd_groups(int64_t rows);
 int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,

@@ -341,3 +341,25 @@ def test_deferred_reductions_match_immediate_ones(monkeypatch):
             assert set(a) == set(b)
             for n in a:
                 assert torch.equal(a[n], b[n]), n
+
+
+def test_stack_rows_matches_cat():
+    """bg_stack_rows (the operand stacking of the batched weight-gradient GEMMs) against torch.cat: contiguous sources, a source with
+    padded rows, bf16 and fp32, more descriptors than one launch holds; a source that is not 16-byte regular takes the cat path."""
+    from branchgan import fused
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for dtype, width in ((torch.bfloat16, 768), (torch.float32, 100)):
+        xs = [torch.randn(37 + i, width, device="cuda", generator=g).to(dtype) for i in range(30)]
+        wide = torch.randn(50, width + 64, device="cuda", generator=g).to(dtype)
+        xs.append(wide[:, :width])                                   # rows 64 elements apart from dense
+        dys = [torch.randn(x.shape[0], 3 * width, device="cuda", generator=g).to(dtype) for x in xs]
+        R = sum(x.shape[0] for x in xs)
+        xa = torch.zeros(R, width, dtype=dtype, device="cuda")
+        da = torch.zeros(R, 3 * width, dtype=dtype, device="cuda")
+        fused._stack_rows(xs, xa, dys, da)
+        assert torch.equal(xa, torch.cat(xs)) and torch.equal(da, torch.cat(dys))
+    odd = [torch.randn(5, 6, device="cuda", generator=g)]             # 24-byte rows: not regular
+    out = torch.zeros(5, 6, device="cuda")
+    dout = torch.zeros(5, 6, device="cuda")
+    fused._stack_rows(odd, out, odd, dout)
+    assert torch.equal(out, odd[0]) and torch.equal(dout, odd[0])
