@@ -30,8 +30,8 @@ h.bg_debug_topp_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 FIRST = os.environ.get("BRANCHGAN_TOPP_FIRST_FORM") == "1"
 NAMES = (["row in registers", "level-1 histogram", "level-1 scan", "level-2 histogram", "level-2 scan", "level-3 histogram",
           "level-3 scan", "count / fit / cut", "noise pass + lists", "merge + store"] if FIRST else
-         ["row in registers", "level-1 histogram", "level-1 scan", "deeper levels", "list stage", None, None, "fit / theta / cut",
-          "kept list", "noise row, keys, merge"])
+         ["row in registers", "level-1 histogram", "level-1 scan", "candidates listed", "levels + ranked list", None, None, "fit / theta",
+          "kept to front, keys, noise row", "merge + store"])
 for p in (0.5, 0.9):
     for _ in range(2):
         ops.topp_select(probs, 4, noise, p, blocked=blocked)

@@ -12,6 +12,8 @@
 // tight bound).  Branch keys (ancestors + self: the same branch point k of each slot on the node's path)
 // are this lane's own rows, so they are handled as per-lane dot products folded into the same online
 // softmax — no 32x wasted diagonal tiles.
+#include <stdlib.h>
+
 #include "attn_common.h"
 
 namespace bg {
@@ -155,11 +157,15 @@ template <typename T, int DH> struct SplitLds {
   static constexpr int V_ELEMS = L::ROW_ELEMS;
   static constexpr size_t WAVE_BYTES = ((size_t)(K_ELEMS + V_ELEMS) * sizeof(T) + 15) / 16 * 16;
   static constexpr size_t MERGE_BYTES = (size_t)ATT_WAVES * (DH + 2) * ATT_TILE * sizeof(float);
-  static constexpr size_t BYTES = (ATT_WAVES * WAVE_BYTES > MERGE_BYTES ? ATT_WAVES * WAVE_BYTES : MERGE_BYTES) + 64;
+  static constexpr size_t STAGE_BYTES = ((ATT_WAVES * WAVE_BYTES > MERGE_BYTES ? ATT_WAVES * WAVE_BYTES : MERGE_BYTES) + 63) / 64 * 64;
+  // the workgroup's own Q tile, fetched once by all 256 threads in whole 16-byte row chunks (as in attn_bwd_split.hip: a lane
+  // that reads its own row from global memory touches 32 cache lines per load instruction, and four waves did it four times)
+  static constexpr size_t Q_BYTES = ((size_t)L::ROW_ELEMS * sizeof(T) + 15) / 16 * 16;
+  static constexpr size_t BYTES = STAGE_BYTES + Q_BYTES + 64;
 };
 
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_fwd_split_kernel(AttnArgs a) {
   using SL = SplitLds<T, DH>;
   constexpr int NDT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -173,14 +179,25 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
   const int rq = blk.x * ATT_TILE + (lane & 31);
   const bool valid = rq < R;
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
-  int ctx = valid ? a.ctx_len[kq] : 0;
-  ctx = min(ctx, sh.S_text);
-
-  const T* q_row = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)kq * sh.q_sk;
   const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
   const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
-  RowFrag<T, DH> qf;
-  qf.load(q_row, valid, h);
+  // ONE round of loads: context length, path, the Q tile and - before the number of key tiles is known - key tile `wave`
+  int ctx = valid ? a.ctx_len[kq] : 0;
+  const int plen = valid ? a.path_len[n] : 0;
+  T* q_l = (T*)(smem + SL::STAGE_BYTES);
+  TileRegs<T, DH, 256> gq;
+  gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, blk.x * ATT_TILE, tid);
+  TileRegs<T, DH, 64> kreg, vreg;
+  if (wave * ATT_TILE < sh.S_text) {
+    kreg.load(kt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
+    vreg.load(vt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
+  }
+  gq.template store<true, false>(q_l, nullptr, tid);
+  __syncthreads();
+  const T* q_row = q_l + (lane & 31) * Lds<T, DH>::RSTRIDE;       // this lane's query row, in LDS (rows past the end are zero)
+  LdsRowFrag<T, DH> qf;
+  qf.load(q_row);
+  ctx = min(ctx, sh.S_text);
 
   int tile_ctx = ctx;
 #pragma unroll
@@ -194,11 +211,6 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
-  TileRegs<T, DH, 64> kreg, vreg;
-  if (wave < ntiles) {
-    kreg.load(kt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
-    vreg.load(vt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
-  }
   for (int t = wave; t < ntiles; t += ATT_WAVES) {
     const int kb = t * ATT_TILE;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
@@ -242,10 +254,9 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_split_kernel(AttnArgs a) 
   }
 
   // branch keys, path entries wave, wave + 4, ...
-  const int plen = valid ? a.path_len[n] : 0;
   for (int p = wave; p < sh.max_path; p += ATT_WAVES) {
     const bool act = p < plen;
-    const int slot = act ? a.path[n * sh.max_path + p] : 0;
+    const int slot = a.path[n * sh.max_path + p];          // in bounds for every p < max_path: no wait on path_len first
     const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
     const T* kr = nullptr;
     const T* vr = nullptr;
@@ -370,7 +381,8 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
   // few query rows per (batch, head): split the keys over the waves (4x the workgroups, 4x shorter chains); many rows:
   // the query-split kernel stages each K/V tile once for four waves (measured crossover at 128 rows, MI355X, Dh 64)
   const int64_t R = (int64_t)sh.NQ * sh.K;
-  const bool split = sh.Dh <= 128 && R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512;
+  static const bool all_split = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_SPLIT_ALL"); return !(e && e[0] == '0'); }();   // A/B runs
+  const bool split = sh.Dh <= 128 && (all_split || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
   if (split) {
     switch (sh.Dh) {
       case 32: launch_fwd_split<T, 32>(a, grid_split, st); break;

@@ -49,6 +49,21 @@ struct WaveList {
       tau_key = tau == 0 ? order_bits_inv(0) : order_bits_inv((uint32_t)(tau >> 32));
     }
   }
+  // every lane may bring one item (0 = none): only the n best of them can enter the list, so they are picked by n rounds of a
+  // wave-wide maximum (items are unique: the index is part of them) instead of offering all 64 one after the other
+  __device__ __forceinline__ void offer_best(u64 mine) {
+    for (int r = 0; r < n; ++r) {
+      u64 mx = mine;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const u64 other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+      }
+      if (mx <= tau) break;                              // wave-uniform (0 = nobody has anything left)
+      offer(mx);
+      if (mine == mx) mine = 0;
+    }
+  }
   // every lane may bring one item (0 = none); offered in lane order
   __device__ __forceinline__ void offer_lanes(u64 mine) {
     u64 bal = __ballot(mine != 0);

@@ -342,7 +342,7 @@ __device__ void scan_sums(const double* sum, int nb, double cum0, float p32, Cro
   }
 }
 
-__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
+__device__ __forceinline__ void topp_regs_row(const ToppArgs& a, const int64_t row) {
   __shared__ double h_sum[4096];
   __shared__ double e_sum[256];
   __shared__ u64 lds_items[(TOPP_THREADS / 64) * BG_MAX_TOPN];
@@ -352,7 +352,6 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
   __shared__ long long sh_idx_cut;
   __shared__ float sh_mass;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row = blockIdx.x;
   const float* p = a.probs + row * a.stride;
   const float* e = a.noise + row * a.noise_stride;
   const int V = (int)a.V, n = a.n;
@@ -658,42 +657,60 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) {
   TOPP_STAMP(10);  // merge + store
 }
 
+__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) { topp_regs_row(a, blockIdx.x); }
 
-// ---- register-resident variant, second form (round 2) ---------------------------------------------------------------------------
+// The rows topp_list_kernel could not do: todo[0] of them, listed in todo[1 ..]; a few persistent workgroups walk the list
+// (normally empty: the launch then costs a few microseconds, not a workgroup of 1024 threads per row).
+__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_todo_kernel(ToppArgs a, const int* todo) {
+  const int count = todo[0];
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    topp_regs_row(a, todo[1 + i] & 0xFFFFFF);
+    __syncthreads();                                     // the next row reuses the shared arrays
+  }
+}
+
+__global__ void topp_reset_kernel(int* todo) { todo[0] = 0; }
+
+// ---- register-resident variant, list form (round 2) -----------------------------------------------------------------------------
 // The first form above spends 77 us on a row of 50304 (benchmarks/probes/topp_trace.py: 8 us for the row, 8 for the noise -
-// and 60 in between: two 4096- and 2048-bucket scans by ONE wave (9 + 4 us), a third histogram level, three more passes over
-// the registers for the multiplicity of the crossing value and the element above it, and a noise pass that pays two IEEE
-// divisions for every one of the 50304 keys (25 us)).  Here:
-//  * below the exponent the levels are 8 bits wide (256 buckets, count + sum; one wave scans them in under a microsecond) and
-//    stop as soon as the crossing bucket holds at most 64 elements - normally after the first: those are compacted into LDS
-//    and ranked by one wave, which yields the crossing value, its multiplicity, the mass above it AND the next value up;
-//  * the noise pass forms a key only for a kept token that can still enter the wave's list: v >= tau_key * mass * e (with a
-//    relative margin far above the two roundings of (v / mass) / e) is a multiplication and a compare; the divisions run for
-//    the few dozen survivors.  A dropped token's key is +0 unless its noise is 0 or NaN: those rows, rows that keep fewer
-//    than n tokens and rows that keep nothing take the first form's pass (every key formed), so the result is the same.
-// Same arithmetic as before: double sums per bucket, fp32 compare against p, ties at the cut in index order.
-#define TOPP_KEPT_CAP 12288      // kept tokens a row may have on the fast path (96 KB of LDS)
-__global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
-  __shared__ double h_sum[4096];
-  __shared__ unsigned h_cnt[256];
+// and 60 in between).  Every instruction executed per ELEMENT of the register-resident row costs 0.35 us (16 waves share the
+// CU's 64 lanes), a CU streams a 200 KB row in no less than 8 us, and one workgroup per CU overlaps nothing by itself.  So:
+//  * level 1 (the exponent; exact integer bucket sums) is the only histogram over the registers.  Everything at or above the
+//    crossing exponent - the only elements that can be kept or decide the cut, a few thousand - is compacted into LDS as
+//    (index, value bits) pairs, each wave filling a region of its own (ballot + popcount, no atomics);
+//  * from there the row's 52 registers are free: all thirteen noise vectors are requested at once and arrive while the
+//    remaining phases run on the list - 8-bit radix levels (count + double sum) until the crossing bucket holds at most 64
+//    values, those ranked by one wave (crossing value, multiplicity, mass above, next value up), kept entries moved to the
+//    front of each region, their keys (v / mass) / e formed with gathered noise;
+//  * the streamed noise row is only checked for 0 / NaN: a dropped token's key is +0 unless its noise is 0 or NaN.
+// Rows this cannot do - p beyond the row's mass, more candidates than the list holds (flat rows, heavy ties), a tie at the
+// cut that the index order must break, fewer than n kept tokens, nothing kept, zero or NaN noise - are FLAGGED in the caller's
+// workspace and redone by the first form in a second launch of a few persistent workgroups: same results.
+#define TOPP_NOISE_EARLY 7                        // noise vectors requested before the candidate pass (registers)
+#define TOPP_REGION 768                           // list entries per wave (16 regions: 96 KB)
+__global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int* todo) {
+  __shared__ u64 big[(TOPP_THREADS / 64) * TOPP_REGION];     // level 1: 256 exponents x 16 replicas of u64 sums; then the regions
   __shared__ double e_sum[256];
+  __shared__ double h_sum[256];
+  __shared__ unsigned h_cnt[256];
   __shared__ unsigned list[64];
   __shared__ unsigned list_n;
   __shared__ u64 lds_items[(TOPP_THREADS / 64) * BG_MAX_TOPN];
   __shared__ Cross cross;
-  __shared__ unsigned red_u[TOPP_THREADS / 64];
-  __shared__ unsigned sh_theta, sh_ntheta, sh_kept, sh_abnormal;
+  __shared__ unsigned red_u[TOPP_THREADS / 64], red_c[TOPP_THREADS / 64];
+  __shared__ unsigned sh_bad, sh_kept;
   __shared__ unsigned l_prefix, l_neq, l_next, l_next_cnt;
-  __shared__ u64 kept_list[TOPP_KEPT_CAP];
   __shared__ double l_cum;
-  __shared__ long long sh_idx_cut;
-  __shared__ float sh_mass;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row = blockIdx.x;
   const float* p = a.probs + row * a.stride;
   const float* e = a.noise + row * a.noise_stride;
   const int V = (int)a.V, n = a.n;
   const float p32 = a.top_p;
+  // workgroup-uniform: the first form redoes this row.  The reason rides in the top byte (rows < 2^24: bg_topp_select checks)
+  auto give_up = [&](int why) {
+    if (tid == 0) todo[1 + atomicAdd(&todo[0], 1)] = (int)row | (why << 24);
+  };
 
   uint32_t blk[BG_MAX_BLOCKED];
 #pragma unroll
@@ -701,12 +718,6 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
     int64_t b = (i < a.n_blocked) ? a.blocked[row * a.n_blocked + i] : -1;
     blk[i] = (b >= 0 && b < a.V) ? (uint32_t)b : 0xFFFFFFFFu;
   }
-  auto value = [&](int i) -> float {                  // global-memory view of element i (rare tie-at-the-cut pass only)
-    float v = p[i];
-    for (int b = 0; b < a.n_blocked; ++b)
-      if (blk[b] == (uint32_t)i) v = 0.f;
-    return v + 0.0f;
-  };
 
   // ---- the row, once: vector c of thread t covers elements (c * 1024 + t) * 4 - mis + {0..3}; outside [0, V): -1 (skipped) ----
   TOPP_STAMP(0);
@@ -730,14 +741,12 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
         if (d == (uint32_t)j && i0 + j >= 0) x[c][j] = 0.f;
     }
   }
-  auto present = [](unsigned u) { return (int)u >= 0; };          // sign bit = padding
   TOPP_STAMP(1);   // row in registers
 
-  // ---- level 1: exponent (bits 30:23), 16 lane-replicas per bucket, sums only ----------------------------------------------------
-  // The values of one exponent are 24-bit integers times one power of two, so a bucket's sum is an INTEGER sum (below 2^40 for
-  // 53245 elements): exact whatever the order, and a 64-bit integer atomic where a double-precision one was.
-  u64* h_int = (u64*)h_sum;
-  for (int i = tid; i < 4096; i += TOPP_THREADS) h_int[i] = 0ull;
+  // ---- level 1: exponent (bits 30:23), 16 lane-replicas per bucket.  The values of one exponent are 24-bit integers times one
+  // power of two, so a bucket's sum is an INTEGER sum (below 2^40 for 53245 elements): exact whatever the order.
+  for (int i = tid; i < 4096; i += TOPP_THREADS) big[i] = 0ull;
+  if (tid == 0) { sh_bad = 0u; sh_kept = 0u; list_n = 0u; }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < TOPP_NV; ++c)
@@ -746,13 +755,13 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
       const float v = x[c][j];
       const unsigned u = __float_as_uint(v);
       const unsigned ex = (u >> 23) & 255u;
-      if (v > 0.f) atomicAdd(&h_int[ex * 16 + (lane & 15)], (u64)((u & 0x7FFFFFu) | (ex ? 0x800000u : 0u)));
+      if (v > 0.f) atomicAdd(&big[ex * 16 + (lane & 15)], (u64)((u & 0x7FFFFFu) | (ex ? 0x800000u : 0u)));
     }
   __syncthreads();
   if (tid < 256) {
     u64 ss = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ss += h_int[tid * 16 + r];
+    for (int r = 0; r < 16; ++r) ss += big[tid * 16 + r];
     e_sum[tid] = ldexp((double)ss, (tid ? tid : 1) - 150);     // exact: ss < 2^53
   }
   __syncthreads();
@@ -760,305 +769,289 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
   if (wave == 0) scan_sums(e_sum, 256, 0.0, p32, &cross, lane, false);
   __syncthreads();
   TOPP_STAMP(3);   // level-1 scan
-  const bool crossing = cross.found != 0;
-  unsigned prefix = 0, n_eq = 0, next_up = 0, next_cnt = 0;     // next_up: the value just above the crossing value (0: not known)
+  if (cross.found == 0) { give_up(1); return; }         // p is not below the row's mass: everything but the last element is kept
+  const unsigned b1 = (unsigned)cross.bucket;
   double cum_gt = cross.cum_before;
-  if (crossing) {
-    prefix = (unsigned)cross.bucket;     // bits 31:23 (sign 0)
-    int shift = 23;
-    unsigned in_bucket = 0xFFFFFFFFu;
-    // ---- deeper levels: 8 + 8 + 7 bits, count and sum, until the crossing bucket is small -------------------------------------
-    for (int lvl = 0; lvl < 3 && in_bucket > 64u; ++lvl) {
-      const int nshift = lvl == 0 ? 15 : (lvl == 1 ? 7 : 0);
-      const unsigned mask = lvl == 2 ? 127u : 255u;
+  if (b1 == 0) { give_up(2); return; }                  // the cut falls among the denormals
+
+  // The noise row is requested while the row is still needed for one more pass - as many vectors as fit beside it in the
+  // registers now, the rest behind that pass - and arrives behind the phases below.  It has the probabilities' misalignment
+  // (checked on the host), so vector c is one aligned 16-byte load; a vector that straddles the row's ends is read whole (the
+  // bytes outside belong to the neighbouring rows or the 16-byte block the row ends in)
+  f32x4 en[TOPP_NV];
+  const char* e_al = (const char*)(e - mis);
+  auto load_noise = [&](int c) __attribute__((always_inline)) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    en[c] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    if (i0 > -4 && i0 < V) en[c] = __builtin_nontemporal_load((const f32x4*)(e_al + (unsigned)((c * TOPP_THREADS + tid) * 16)));
+  };
+#pragma unroll
+  for (int c = 0; c < TOPP_NOISE_EARLY; ++c) load_noise(c);
+  // ---- everything at or above the crossing exponent goes to this wave's region of the list (no atomics) -----------------------
+  u64* region = big + wave * TOPP_REGION;
+  unsigned mine = 0;                                   // wave-uniform count
+  const unsigned lowest = b1 << 23;                  // positive floats order like their bit patterns
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) any |= (int)__float_as_uint(x[c][j]) >= (int)lowest;    // the padding (-1) is negative as an int
+    if (__ballot(any) == 0) continue;                    // most vectors of a peaked row hold no candidate
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = __float_as_uint(x[c][j]);
+      const bool hit = (int)u >= (int)lowest;
+      const unsigned long long bal = __ballot(hit);
+      if (bal == 0) continue;
+      const unsigned pos = mine + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+      if (hit && pos < TOPP_REGION) region[pos] = ((u64)(uint32_t)(i0 + j) << 32) | u;
+      mine += (unsigned)__popcll(bal);
+    }
+  }
+  if (mine > TOPP_REGION && lane == 0) atomicOr(&sh_bad, 1u);
+  // the registers of the row are free from here: the rest of the noise row is requested now
+#pragma unroll
+  for (int c = TOPP_NOISE_EARLY; c < TOPP_NV; ++c) load_noise(c);
+  if (tid < 256) { h_sum[tid] = 0.0; h_cnt[tid] = 0u; }
+  __syncthreads();
+  if (sh_bad) { give_up(3); return; }
+  TOPP_STAMP(4);   // candidates listed
+  const unsigned cnt = min(mine, (unsigned)TOPP_REGION);
+
+  // ---- radix levels of 8 + 8 + 7 bits below the exponent, on the list, until the crossing bucket is small -----------------------
+  unsigned prefix = b1, n_eq = 0, next_up = 0, next_cnt = 0;
+  int shift = 23;
+  unsigned in_bucket = 0xFFFFFFFFu;
+  for (int lvl = 0; lvl < 3 && in_bucket > 64u; ++lvl) {
+    const int nshift = lvl == 0 ? 15 : (lvl == 1 ? 7 : 0);
+    const unsigned mask = lvl == 2 ? 127u : 255u;
+    for (unsigned i = lane; i < cnt; i += 64) {
+      const unsigned u = (unsigned)region[i];
+      if ((u >> shift) == prefix) {
+        atomicAdd(&h_cnt[(u >> nshift) & mask], 1u);
+        atomicAdd(&h_sum[(u >> nshift) & mask], (double)__uint_as_float(u));
+      }
+    }
+    __syncthreads();
+    if (wave == 0) scan_buckets(h_cnt, h_sum, 256, cum_gt, 0u, p32, &cross, lane, true);
+    __syncthreads();
+    prefix = (prefix << (lvl == 2 ? 7 : 8)) | (unsigned)cross.bucket;
+    shift = nshift;
+    cum_gt = cross.cum_before;
+    in_bucket = h_cnt[cross.bucket];
+    __syncthreads();
+    if (in_bucket > 64u && lvl < 2) {
       if (tid < 256) { h_sum[tid] = 0.0; h_cnt[tid] = 0u; }
       __syncthreads();
-#pragma unroll
-      for (int c = 0; c < TOPP_NV; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = x[c][j];
-          asm volatile("" : "+v"(v));                    // opaque per level: else all 52 (double)v are hoisted out of the level loop (104 registers)
-          const unsigned u = __float_as_uint(v);
-          const bool hit = v > 0.f && (u >> shift) == prefix;
-          const unsigned b = (u >> nshift) & mask;
-          // heavy ties: when many lanes of the wave go to ONE bucket the wave adds once (50k serialised atomics otherwise)
-          const unsigned long long act = __ballot(hit);
-          if (act == 0) continue;
-          const int pc = __popcll(act);
-          bool done = false;
-          if (pc >= 16) {
-            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)b, __ffsll(act) - 1);
-            if (__ballot(hit && b != b0) == 0) {
-              // all hits carry values of one bucket; equal bucket at the last level = equal value, else the sum is taken in lane order
-              double s2 = hit ? (double)v : 0.0;
-#pragma unroll
-              for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-              if (lane == 0) { atomicAdd(&h_cnt[b0], (unsigned)pc); atomicAdd(&h_sum[b0], s2); }
-              done = true;
-            }
-          }
-          if (!done && hit) { atomicAdd(&h_cnt[b], 1u); atomicAdd(&h_sum[b], (double)v); }
-        }
-      __syncthreads();
-      if (wave == 0) scan_buckets(h_cnt, h_sum, 256, cum_gt, 0u, p32, &cross, lane, true);
-      __syncthreads();
-      prefix = (prefix << (lvl == 2 ? 7 : 8)) | (unsigned)cross.bucket;
-      shift = nshift;
-      cum_gt = cross.cum_before;
-      in_bucket = h_cnt[cross.bucket];
-      __syncthreads();
-    }
-    TOPP_STAMP(4);   // deeper levels
-    if (shift == 0) {
-      n_eq = in_bucket;                                  // all 31 bits resolved: the bucket is one value
-    } else {
-      // ---- the crossing bucket's elements (at most 64) in LDS, ranked by wave 0 ---------------------------------------------
-      if (tid == 0) list_n = 0;
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < TOPP_NV; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned u = __float_as_uint(x[c][j]);
-          if (x[c][j] > 0.f && (u >> shift) == prefix) {
-            const unsigned pos = atomicAdd(&list_n, 1u);
-            if (pos < 64u) list[pos] = u;
-          }
-        }
-      __syncthreads();
-      if (wave == 0) {
-        const int cnt = (int)min(list_n, 64u);
-        const unsigned ui = lane < cnt ? list[lane] : 0u;
-        const double vi = (double)__uint_as_float(ui);
-        double gt_sum = 0.0;
-        unsigned eqc = 0;
-        for (int j2 = 0; j2 < cnt; ++j2) {
-          const unsigned uj = list[j2];
-          gt_sum += (uj > ui) ? (double)__uint_as_float(uj) : 0.0;
-          eqc += (uj == ui) ? 1u : 0u;
-        }
-        const bool cr = lane < cnt && (float)(cum_gt + gt_sum + (double)eqc * vi) > p32;
-        unsigned best = cr ? ui : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
-        if (best == 0u) {                                // the parent bucket crossed, a last-bit difference of the re-summed
-          best = lane < cnt ? ui : 0xFFFFFFFFu;          // values must not lose it: cross at the smallest value
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
-        }
-        unsigned nxt = (lane < cnt && ui > best) ? ui : 0xFFFFFFFFu;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, o));
-        const unsigned long long is_best = __ballot(lane < cnt && ui == best);
-        const unsigned long long is_next = __ballot(lane < cnt && ui == nxt);
-        if (lane == __ffsll(is_best) - 1) {
-          l_prefix = ui; l_neq = eqc; l_cum = cum_gt + gt_sum;
-          l_next = nxt == 0xFFFFFFFFu ? 0u : nxt;
-          l_next_cnt = (unsigned)__popcll(is_next);
-        }
-      }
-      __syncthreads();
-      prefix = l_prefix; n_eq = l_neq; cum_gt = l_cum; next_up = l_next; next_cnt = l_next_cnt;
     }
   }
-  TOPP_STAMP(5);   // list stage
+  if (shift == 0) {
+    n_eq = in_bucket;                                  // all 31 bits resolved: the bucket is one value
+  } else {
+    for (unsigned i = lane; i < cnt; i += 64) {
+      const unsigned u = (unsigned)region[i];
+      if ((u >> shift) == prefix) {
+        const unsigned pos = atomicAdd(&list_n, 1u);
+        if (pos < 64u) list[pos] = u;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int lc = (int)min(list_n, 64u);
+      const unsigned ui = lane < lc ? list[lane] : 0u;
+      const double vi = (double)__uint_as_float(ui);
+      double gt_sum = 0.0;
+      unsigned eqc = 0;
+      for (int j2 = 0; j2 < lc; ++j2) {
+        const unsigned uj = list[j2];
+        gt_sum += (uj > ui) ? (double)__uint_as_float(uj) : 0.0;
+        eqc += (uj == ui) ? 1u : 0u;
+      }
+      const bool cr = lane < lc && (float)(cum_gt + gt_sum + (double)eqc * vi) > p32;
+      unsigned best = cr ? ui : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+      if (best == 0u) {                                // the parent bucket crossed, a last-bit difference of the re-summed
+        best = lane < lc ? ui : 0xFFFFFFFFu;           // values must not lose it: cross at the smallest value
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+      }
+      unsigned nxt = (lane < lc && ui > best) ? ui : 0xFFFFFFFFu;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, (unsigned)__shfl_xor((int)nxt, o));
+      const unsigned long long is_best = __ballot(lane < lc && ui == best);
+      const unsigned long long is_next = __ballot(lane < lc && ui == nxt);
+      if (lane == __ffsll(is_best) - 1) {
+        l_prefix = ui; l_neq = eqc; l_cum = cum_gt + gt_sum;
+        l_next = nxt == 0xFFFFFFFFu ? 0u : nxt;
+        l_next_cnt = (unsigned)__popcll(is_next);
+      }
+    }
+    __syncthreads();
+    prefix = l_prefix; n_eq = l_neq; cum_gt = l_cum; next_up = l_next; next_cnt = l_next_cnt;
+  }
+  TOPP_STAMP(5);   // levels + ranked list
 
   // ---- how many copies of the crossing value tau still fit (sequential double adds of tau in the reference) -------------
+  const double tau = (double)__uint_as_float(prefix);
   unsigned c_fit = 0;
-  const double tau = crossing ? (double)__uint_as_float(prefix) : 0.0;
-  if (crossing) {
-    if (tau == 0.0) c_fit = n_eq;
-    else {
-      double guess = floor(((double)p32 - cum_gt) / tau);
-      long long c0 = guess < 0 ? 0 : (guess > (double)n_eq ? (long long)n_eq : (long long)guess);
-      while (c0 < (long long)n_eq && (float)(cum_gt + (double)(c0 + 1) * tau) <= p32) ++c0;
-      while (c0 > 0 && (float)(cum_gt + (double)c0 * tau) > p32) --c0;
-      c_fit = (unsigned)c0;
-    }
+  {
+    double guess = floor(((double)p32 - cum_gt) / tau);
+    long long c0 = guess < 0 ? 0 : (guess > (double)n_eq ? (long long)n_eq : (long long)guess);
+    while (c0 < (long long)n_eq && (float)(cum_gt + (double)(c0 + 1) * tau) <= p32) ++c0;
+    while (c0 > 0 && (float)(cum_gt + (double)c0 * tau) > p32) --c0;
+    c_fit = (unsigned)c0;
   }
+  // M = everything above tau + c_fit copies of tau fit; kept = the M - 1 best = everything ranked strictly better than e*
   unsigned theta, r, n_theta;
   double e_star;
-  bool none_kept = false;
-  if (crossing && c_fit >= 1) {
+  if (c_fit >= 1) {
     theta = prefix; r = c_fit - 1; n_theta = n_eq; e_star = tau;
-  } else if (crossing && next_up != 0u) {                // e* = the worst-ranked element above tau: the list knows it
+  } else if (next_up != 0u) {                          // e* = the worst-ranked element above tau: the ranked list knows it
     theta = next_up; n_theta = next_cnt; r = n_theta - 1; e_star = (double)__uint_as_float(theta);
   } else {
-    // smallest value above tau (of the whole row when nothing crossed), then how often it occurs.  (One pass that carries
-    // (min, count) pairs through the lanes was slower: 16 waves share the CU's 64 lanes, every instruction per element is 0.35 us.)
-    const unsigned lo = crossing ? prefix : 0u;
-    unsigned mn = 0xFFFFFFFFu;
+    // smallest value above tau and how often it occurs, from the list (it holds everything at or above tau's exponent)
+    unsigned mn = 0xFFFFFFFFu, mc = 0u;
+    for (unsigned i = lane; i < cnt; i += 64) {
+      const unsigned u = (unsigned)region[i];
+      if (u > prefix) { mc = u < mn ? 1u : (mc + (u == mn ? 1u : 0u)); mn = min(mn, u); }
+    }
 #pragma unroll
-    for (int c = 0; c < TOPP_NV; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned u = __float_as_uint(x[c][j]);
-        if (present(u) && (!crossing || u > lo) && u < mn) mn = u;
-      }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
-    if (lane == 0) red_u[wave] = mn;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned om = (unsigned)__shfl_xor((int)mn, o), oc = (unsigned)__shfl_xor((int)mc, o);
+      mc = om < mn ? oc : (om == mn ? mc + oc : mc);
+      mn = min(mn, om);
+    }
+    if (lane == 0) { red_u[wave] = mn; red_c[wave] = mc; }
     __syncthreads();
-    if (tid == 0) {
-      unsigned m2 = red_u[0];
-      for (int w = 1; w < TOPP_THREADS / 64; ++w) m2 = min(m2, red_u[w]);
-      sh_theta = m2;
+    mn = red_u[0]; mc = red_c[0];
+#pragma unroll 1
+    for (int w = 1; w < TOPP_THREADS / 64; ++w) {
+      const unsigned om = red_u[w], oc = red_c[w];
+      mc = om < mn ? oc : (om == mn ? mc + oc : mc);
+      mn = min(mn, om);
+    }
+    if (mn == 0xFFFFFFFFu) {
+      // tau is the row's maximum (its mass alone exceeds p): nothing is kept, the mass is 0 and every key is (0 / 0) / e = NaN -
+      // all equal, so the n lowest indices win (NaN sorts first, ties by index)
+      if (tid < n) {
+        a.out_ids[row * n + tid] = tid;
+        if (a.out_keys) a.out_keys[row * n + tid] = __uint_as_float(0x7FC00000u);
+      }
+      return;
+    }
+    theta = mn; n_theta = mc; r = n_theta - 1; e_star = (double)__uint_as_float(theta);
+  }
+  const float mass = (float)(cum_gt + (double)c_fit * tau - e_star);
+  if (mass == 0.f) {
+    // Nothing is kept (the element above tau is the row's maximum and e* itself): every key is (0 / 0) / e = NaN - all equal,
+    // so the n lowest indices win (NaN sorts first, ties by index)
+    if (tid < n) {
+      a.out_ids[row * n + tid] = tid;
+      if (a.out_keys) a.out_keys[row * n + tid] = __uint_as_float(0x7FC00000u);
+    }
+    return;
+  }
+  if (!(mass > 0.f) || !(mass < INFINITY)) { give_up(5); return; }
+  // r == 0: none of the theta-valued elements is kept.  0 < r < n_theta: a tie AT the cut - the first r of them in index order
+  // are kept: their indices go to a small shared list and the r-th smallest is the last one in
+  int idx_cut = -1;
+  if (r > 0) {
+    if (n_theta > 64u) { give_up(4); return; }
+    __syncthreads();
+    if (tid == 0) list_n = 0u;
+    __syncthreads();
+    for (unsigned i = lane; i < cnt; i += 64) {
+      const u64 ent = region[i];
+      if ((unsigned)ent == theta) list[atomicAdd(&list_n, 1u) & 63u] = (unsigned)(ent >> 32);
     }
     __syncthreads();
-    theta = sh_theta;
-    if (theta == 0xFFFFFFFFu) { none_kept = true; r = 0; n_theta = 0; e_star = 0.0; }
-    else {
-      unsigned cc = 0;
-#pragma unroll
-      for (int c = 0; c < TOPP_NV; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cc += (__float_as_uint(x[c][j]) == theta) ? 1u : 0u;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cc += __shfl_xor((int)cc, o);
-      __syncthreads();
-      if (lane == 0) red_u[wave] = cc;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned t2 = 0;
-        for (int w = 0; w < TOPP_THREADS / 64; ++w) t2 += red_u[w];
-        sh_ntheta = t2;
-      }
-      __syncthreads();
-      n_theta = sh_ntheta;
-      r = n_theta - 1;
-      e_star = (double)__uint_as_float(theta);
+    if (tid < (int)n_theta) {
+      const unsigned mine_idx = list[tid];
+      unsigned below = 0;
+      for (unsigned j2 = 0; j2 < n_theta; ++j2) below += list[j2] < mine_idx ? 1u : 0u;
+      if (below == r - 1) l_next = mine_idx;             // (l_next is free by now)
     }
+    __syncthreads();
+    idx_cut = (int)l_next;
   }
-  const double fit_mass = cum_gt + (double)c_fit * tau;
-  if (tid == 0) {
-    sh_mass = none_kept ? 0.0f : (float)(fit_mass - e_star);
-    sh_idx_cut = (r == 0) ? -1 : (long long)V;
-    sh_kept = 0u;
-    sh_abnormal = 0u;
-  }
-  __syncthreads();
-  if (!none_kept && r > 0 && r < n_theta && wave == 0) {     // ties at the cut: the r-th theta-valued element in index order
-    unsigned running = 0;
-    long long cut = V;
-    for (int base = 0; base < V; base += 64) {
-      const int i = base + lane;
-      const bool eq = (i < V) && (__float_as_uint(value(i)) == theta);
-      const unsigned long long bal = __ballot(eq);
-      const unsigned c = (unsigned)__popcll(bal);
-      if (running + c >= r) {
-        unsigned need = r - running;
-        unsigned long long m = bal;
-        for (unsigned k = 1; k < need; ++k) m &= m - 1;
-        cut = base + (__ffsll(m) - 1);
-        break;
-      }
-      running += c;
-    }
-    if (lane == 0) sh_idx_cut = cut;
-  }
-  __syncthreads();
-  const int idx_cut = (int)sh_idx_cut;                 // -1 .. V: fits
-  const float mass = sh_mass;
-  TOPP_STAMP(8);   // fit, theta, cut
+  const unsigned keep_from = theta + 1u;                 // plus the theta-valued entries up to idx_cut
+  TOPP_STAMP(8);   // fit, theta
 
-  // ---- the kept tokens, compacted: (value bits, index) pairs in LDS.  After this the row's registers are free. ---------------
-  if (!none_kept) {
-#pragma unroll
-    for (int c = 0; c < TOPP_NV; ++c) {
-      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned u = __float_as_uint(x[c][j]);
-        const bool kept = present(u) & ((u > theta) | ((u == theta) & (i0 + j <= idx_cut)));
-        const unsigned long long bal = __ballot(kept);
-        if (bal == 0) continue;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&sh_kept, (unsigned)__popcll(bal));
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-        if (kept && pos < TOPP_KEPT_CAP) kept_list[pos] = ((u64)(uint32_t)(i0 + j) << 32) | u;
-      }
-    }
+  // ---- kept entries to the front of each region, their keys with gathered noise, top-n per wave -------------------------------
+  unsigned kept_w = 0;
+  for (unsigned i0 = 0; i0 < cnt; i0 += 64) {
+    const unsigned i = i0 + lane;
+    const u64 ent = i < cnt ? region[i] : 0ull;
+    const bool kept = i < cnt && ((unsigned)ent >= keep_from || ((unsigned)ent == theta && (int)(uint32_t)(ent >> 32) <= idx_cut));
+    const unsigned long long bal = __ballot(kept);
+    const unsigned pos = kept_w + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the chunk is in registers before its slots are overwritten
+    if (kept) region[pos] = ent;
+    kept_w += (unsigned)__popcll(bal);
   }
-  __syncthreads();
-  const unsigned K = sh_kept;
-  TOPP_STAMP(9);   // kept list
-  // The fast pass needs at least n kept tokens (else the zero keys of dropped tokens fill the list, in index order), a list
-  // that fits, a finite positive mass - and noise without zeros or NaNs: a dropped token's key is (+0 / mass) / e = +0 unless e
-  // is 0 or NaN, then it is NaN and sorts first.  The whole noise row is read once to see that; the keys come from the list.
-  bool slow = none_kept || K < (unsigned)n || K > TOPP_KEPT_CAP || !(mass > 0.f) || !(mass < INFINITY);
+  if (lane == 0) atomicAdd(&sh_kept, kept_w);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   WaveList wl;
   wl.init(n, lane);
-  const char* e_al = (const char*)(e - mis);           // the probabilities' misalignment (checked on the host): aligned vectors
-  if (!slow) {
-    f32x4 en[TOPP_NV];
+  for (unsigned i0 = 0; i0 < kept_w; i0 += 256) {      // four entries per lane with their noise loads in flight together
+    u64 ent[4];
+    float ev[4];
 #pragma unroll
-    for (int c = 0; c < TOPP_NV; ++c) {
-      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-      en[c] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-      // a vector that straddles the row's ends is read whole: the bytes outside belong to the neighbouring rows or to the
-      // 16-byte block the row ends in; its outside elements are ignored below
-      if (i0 > -4 && i0 < V) en[c] = __builtin_nontemporal_load((const f32x4*)(e_al + (unsigned)((c * TOPP_THREADS + tid) * 16)));
+    for (int k = 0; k < 4; ++k) {
+      const unsigned i = i0 + k * 64 + lane;
+      ent[k] = i < kept_w ? region[i] : 0ull;
+      ev[k] = i < kept_w ? e[(uint32_t)(ent[k] >> 32)] : 1.0f;
     }
-    // keys of the kept tokens while the row is in flight: thread t takes entries t, t + 1024, ...
-    for (unsigned t0 = 0; t0 < K; t0 += TOPP_THREADS) {
-      const unsigned t = t0 + tid;
-      u64 mine = 0;
-      if (t < K) {
-        const u64 ent = kept_list[t];
-        const uint32_t idx = (uint32_t)(ent >> 32);
-        const float v = __uint_as_float((uint32_t)ent);
-        const u64 it = make_item((v / mass) / e[idx], idx);
-        mine = it > wl.tau ? it : 0;
-      }
-      wl.offer_lanes(mine);
-    }
-    bool abnormal = false;
 #pragma unroll
-    for (int c = 0; c < TOPP_NV; ++c) {
-      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) abnormal |= (i0 + j >= 0) & (i0 + j < V) & !(fabsf(en[c][j]) > 0.f);
-    }
-    if (__ballot(abnormal) != 0 && lane == 0) atomicOr(&sh_abnormal, 1u);
-    __syncthreads();
-    slow = sh_abnormal != 0u;
-  }
-  if (slow) {
-    // every key formed, row and noise read again a vector at a time: rows that keep fewer than n tokens are filled from the zero
-    // keys in index order, rows that keep nothing are all NaN, and a zero or NaN noise value makes a dropped token's key NaN
-    wl.init(n, lane);
-    const float zero_over_mass = 0.f / mass;               // +0, or NaN when nothing is kept
-    for (int c = 0; c < TOPP_NV; ++c) {
-      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-      u64 it[4];
-      uint32_t cmask = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool in = i0 + j >= 0 && i0 + j < V;
-        const float v = in ? value(i0 + j) : -1.0f;
-        const float ej = in ? e[i0 + j] : 1.0f;
-        const unsigned u = __float_as_uint(v);
-        const bool kept = !none_kept && (u > theta || (u == theta && (i0 + j) <= idx_cut));
-        const float key = kept ? (v / mass) / ej : zero_over_mass / ej;
-        it[j] = make_item(key, (uint32_t)(i0 + j));
-        cmask |= (in && it[j] > wl.tau) ? (1u << j) : 0u;
+    for (int k = 0; k < 4; ++k) {
+      u64 it = 0;
+      if (i0 + k * 64 + lane < kept_w) {
+        it = make_item((__uint_as_float((uint32_t)ent[k]) / mass) / ev[k], (uint32_t)(ent[k] >> 32));
+        it = it > wl.tau ? it : 0;
       }
-      while (__ballot(cmask != 0)) {
-        u64 mine = 0;
-        if (cmask) {
-          const int j = __ffs(cmask) - 1;
-          cmask &= cmask - 1;
-          mine = j == 0 ? it[0] : (j == 1 ? it[1] : (j == 2 ? it[2] : it[3]));
-        }
-        wl.offer_lanes(mine);
-      }
+      wl.offer_best(it);
     }
   }
+  // the streamed noise: a dropped token's key is (+0 / mass) / e = +0 unless e is 0 or NaN
+  bool abnormal = false;
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) abnormal |= (i0 + j >= 0) & (i0 + j < V) & !(fabsf(en[c][j]) > 0.f);
+  }
+  if (__ballot(abnormal) != 0 && lane == 0) atomicOr(&sh_bad, 1u);
   if (lane < n) lds_items[wave * n + lane] = wl.item;
   __syncthreads();
+  TOPP_STAMP(9);   // keys, noise row
+  if (sh_bad) { give_up(6); return; }
   rank_merge_store(lds_items, (TOPP_THREADS / 64) * n, n, a.out_ids + row * n, a.out_keys ? a.out_keys + row * n : nullptr, nullptr);
+  const unsigned K = sh_kept;
+  if (K < (unsigned)n && wave == 0) {
+    // Fewer kept tokens than samples: the rest of the list are dropped tokens, whose keys are all +0 (the noise row holds no 0 /
+    // NaN here) - the lowest indices that are not kept, in index order.  They lie below n + K <= 127: lane l tests l and l + 64.
+    const int items = (TOPP_THREADS / 64) * n;
+    bool kept_lo = false, kept_hi = false;
+    for (int i = 0; i < items; ++i) {
+      const u64 it = lds_items[i];
+      const uint32_t idx = 0xFFFFFFFFu - (uint32_t)it;
+      kept_lo |= it != 0 && idx == (uint32_t)lane;
+      kept_hi |= it != 0 && idx == (uint32_t)(lane + 64);
+    }
+    const unsigned long long free_lo = __ballot(!kept_lo && lane < V), free_hi = __ballot(!kept_hi && lane + 64 < V);
+    const unsigned below = (unsigned)__popcll(free_lo & ((1ull << lane) - 1ull));
+    const unsigned pos_lo = K + below, pos_hi = K + (unsigned)__popcll(free_lo) + (unsigned)__popcll(free_hi & ((1ull << lane) - 1ull));
+    if (!kept_lo && lane < V && pos_lo < (unsigned)n) {
+      a.out_ids[row * n + pos_lo] = lane;
+      if (a.out_keys) a.out_keys[row * n + pos_lo] = 0.f;
+    }
+    if (!kept_hi && lane + 64 < V && pos_hi < (unsigned)n) {
+      a.out_ids[row * n + pos_hi] = lane + 64;
+      if (a.out_keys) a.out_keys[row * n + pos_hi] = 0.f;
+    }
+  }
   TOPP_STAMP(10);  // merge + store
 }
 
@@ -1067,14 +1060,13 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_fast_kernel(ToppArgs a) {
 using namespace bg;
 
 extern "C" size_t bg_topp_workspace_bytes(int64_t rows, int64_t V, int n) {
-  (void)rows; (void)V; (void)n;
-  return 0;
+  (void)n;
+  return (V + 3 <= TOPP_CAP && rows > 0) ? (size_t)(rows + 1) * sizeof(int) : 0;     // the rows left to the first form: count + list
 }
 
 extern "C" int bg_topp_select(const float* probs, int64_t rows, int64_t V, int64_t row_stride, const float* noise,
                               int64_t noise_row_stride, const int64_t* blocked, int n_blocked, float top_p, int n,
                               int64_t* out_ids, float* out_keys, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   BG_REQUIRE(probs && noise && out_ids, "bg_topp_select: null probs/noise/out_ids");
   BG_REQUIRE(rows > 0 && rows < (1ll << 31) && V > 0 && V < (1ll << 31), "bg_topp_select: rows=%lld V=%lld", (long long)rows, (long long)V);
   BG_REQUIRE(n >= 1 && n <= BG_MAX_TOPN && n <= V, "bg_topp_select: n=%d must be in [1, min(%d, V)]", n, BG_MAX_TOPN);
@@ -1083,11 +1075,18 @@ extern "C" int bg_topp_select(const float* probs, int64_t rows, int64_t V, int64
   BG_REQUIRE(top_p == top_p, "bg_topp_select: top_p is NaN");
   ToppArgs a{probs, noise, blocked, V, row_stride, noise_row_stride, n, n_blocked, top_p, out_ids, out_keys};
   static const bool first_form = [] { const char* e = getenv("BRANCHGAN_TOPP_FIRST_FORM"); return e && e[0] == '1'; }();   // A/B runs
-  if (V + 3 <= TOPP_CAP && first_form) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
-  else if (V + 3 <= TOPP_CAP && ((uintptr_t)noise - (uintptr_t)probs) % 16 == 0 && ((noise_row_stride - row_stride) * 4) % 16 == 0)
-    hipLaunchKernelGGL(topp_fast_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
-  else if (V + 3 <= TOPP_CAP) hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(topp_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (V + 3 > TOPP_CAP) {
+    hipLaunchKernelGGL(topp_kernel, dim3((unsigned)rows), dim3(256), 0, st, a);
+  } else if (!first_form && rows < (1 << 24) && workspace && workspace_bytes >= (size_t)(rows + 1) * sizeof(int) && (uintptr_t)workspace % 4 == 0 &&
+             ((uintptr_t)noise - (uintptr_t)probs) % 16 == 0 && ((noise_row_stride - row_stride) * 4) % 16 == 0) {
+    // list form; the rows it cannot do are listed in the workspace and redone by the first form
+    hipLaunchKernelGGL(topp_reset_kernel, dim3(1), dim3(1), 0, st, (int*)workspace);
+    hipLaunchKernelGGL(topp_list_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, st, a, (int*)workspace);
+    hipLaunchKernelGGL(topp_regs_todo_kernel, dim3((unsigned)(rows < 64 ? rows : 64)), dim3(TOPP_THREADS), 0, st, a, (const int*)workspace);
+  } else {
+    hipLaunchKernelGGL(topp_regs_kernel, dim3((unsigned)rows), dim3(TOPP_THREADS), 0, st, a);
+  }
   BG_CHECK_LAUNCH("bg_topp_select");
   return BG_OK;
 }
