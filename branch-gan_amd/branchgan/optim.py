@@ -132,7 +132,10 @@ class ArenaAdam(torch.optim.Optimizer):
             # every rank gets every slice of the fp32 parameters; the low-precision copies are re-rounded here (6 B per parameter
             # of HBM traffic against 2 B per parameter over the links) and the local gradients, consumed by nobody, are cleared
             from .training import all_gather_slices
-            all_gather_slices(self.param_arena, self.param_arena[lo:hi].clone(), ga.group)
+            if getattr(self, "_slice_out", None) is None or self._slice_out.numel() != hi - lo:
+                self._slice_out = torch.empty(hi - lo, dtype=torch.float32, device=self.param_arena.device)
+            self._slice_out.copy_(self.param_arena[lo:hi])
+            all_gather_slices(self.param_arena, self._slice_out, ga.group)
             if lp is not None:
                 lp.copy_(self.param_arena)
             ga.arena.zero_()

@@ -108,13 +108,14 @@ def reduce_scatter_sum(out, inp, group=None, async_op=True):
 
 
 def all_gather_slices(full, mine, group=None):
-    """full = the ranks' `mine` slices one after the other (blocking)."""
+    """full = the ranks' `mine` slices one after the other.  Enqueued like the gradient collectives (async_op + wait on the
+    calling stream), `mine` a buffer that outlives the call."""
     if _through_host(full, group):
         o = torch.empty(full.shape, dtype=full.dtype)
         dist.all_gather_into_tensor(o, mine.cpu(), group=group)
         full.copy_(o)
         return
-    dist.all_gather_into_tensor(full, mine, group=group)
+    dist.all_gather_into_tensor(full, mine, group=group, async_op=True).wait()
 
 
 class GradArena:

@@ -31,7 +31,8 @@ def test_workspace_queries_are_host_only():
     lib = _capi.lib()
     assert lib.bg_topn_workspace_bytes(8192, 50304, 16) == 0                       # enough rows: no split, no workspace
     assert lib.bg_topn_workspace_bytes(256, 50304, 4) == 256 * 8 * 4 * 8           # 8 splits x n x u64
-    assert lib.bg_topp_workspace_bytes(256, 50304, 4) == 0
+    assert lib.bg_topp_workspace_bytes(256, 50304, 4) == (256 + 1) * 4             # list form: count + one id per row left over
+    assert lib.bg_topp_workspace_bytes(256, 1 << 20, 4) == 0                       # beyond the list form's row length: none
 
 
 def test_argument_validation_happens_before_any_launch():
