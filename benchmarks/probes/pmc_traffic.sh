@@ -17,5 +17,5 @@ P=$R/profiles
 # attn_mix: 1 recording step + `reps` replays; the eager steps before the recording launch the same kernels: count launches from the log
 python3 $R/benchmarks/pmc_traffic.py $O/attn_bwd_FETCH_SIZE $O/attn_bwd_WRITE_SIZE $P/r2_pmc_attn_bwd_c2.json -1 "bg_branch_attn_bwd (one-launch kernel; bf16, configs[1] launch mix)" branch_attn_bwd
 python3 $R/benchmarks/pmc_traffic.py $O/attn_fwd_FETCH_SIZE $O/attn_fwd_WRITE_SIZE $P/r2_pmc_attn_fwd_c2.json -1 "bg_branch_attn_fwd (fwd + fwd_split kernels; bf16, configs[1] launch mix)" branch_attn_fwd
-python3 $R/benchmarks/pmc_traffic.py $O/sampling_FETCH_SIZE $O/sampling_WRITE_SIZE $P/r2_pmc_topp.json 3 "bg_topp_select (topp_fast_kernel), 8192 x 50304 fp32, p 0.9, n 4" topp_
+python3 $R/benchmarks/pmc_traffic.py $O/sampling_FETCH_SIZE $O/sampling_WRITE_SIZE $P/r2_pmc_topp.json 3 "bg_topp_select (topp_reset + topp_list + topp_regs_todo kernels), 8192 x 50304 fp32, p 0.9, n 4" topp_
 python3 $R/benchmarks/pmc_traffic.py $O/sampling_FETCH_SIZE $O/sampling_WRITE_SIZE $P/r2_pmc_topn.json 6 "bg_topn_select (TOP_K and SAMPLE_NO_REPLACEMENT launches together), 8192 x 50304 fp32, n 4" topn_
