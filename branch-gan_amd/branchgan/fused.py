@@ -254,9 +254,10 @@ def supported_width(C_):
 # ---------------------------------------------------------------------------------------------------------------------
 # LayerNorm (+ residual add)
 # ---------------------------------------------------------------------------------------------------------------------
-def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None):
+def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None):
     rows, C_ = x2.shape
-    y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
+    if y is None:
+        y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
     x_out = torch.empty_like(x2) if delta2 is not None else None
@@ -267,10 +268,15 @@ def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None):
     return x_out, y, mean, rstd
 
 
-def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None):
+def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None, delta_from=None):
     rows, C_ = x2.shape
     dx = torch.empty_like(x2)
-    dx_lp = torch.empty((rows, C_), dtype=lp_dtype, device=x2.device) if lp_dtype not in (None, torch.float32) else None
+    dx_lp = None
+    if lp_dtype not in (None, torch.float32):
+        if delta_from is not None:          # the gradient of the projection that produced delta: into its dy stack
+            dx_lp = _deferred_dw_for(x2.device).dy_slab(delta_from[0], delta_from[1], rows, C_, lp_dtype)
+        if dx_lp is None:
+            dx_lp = torch.empty((rows, C_), dtype=lp_dtype, device=x2.device)
     dg, dg_ret = _grad_buffer(gamma_p)
     db, db_ret = _grad_buffer(beta_p)
     dc, dc_ret = _grad_buffer(colsum_p) if colsum_p is not None else (None, None)
@@ -295,9 +301,9 @@ def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, out_dtype, y_buf=None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        _, y, mean, rstd = _ln_fwd(x2, None, gamma.detach(), beta.detach(), eps, out_dtype)
+        _, y, mean, rstd = _ln_fwd(x2, None, gamma.detach(), beta.detach(), eps, out_dtype, y=y_buf[0] if y_buf else None)
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params = (gamma, beta)
         return y.view(x.shape)
@@ -307,7 +313,7 @@ class _LayerNorm(torch.autograd.Function):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
         dx, _, dg, db, _ = _ln_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, gamma, beta, None, None)
-        return dx.view(dy.shape), dg, db, None, None
+        return dx.view(dy.shape), dg, db, None, None, None
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -316,14 +322,15 @@ class _AddLayerNorm(torch.autograd.Function):
     delta's gradient, which this backward has in registers anyway - the projection is then built with bias_grad=False."""
 
     @staticmethod
-    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias, delta_b):
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias, delta_b, y_buf=None, delta_from=None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         d2 = delta.reshape(x2.shape).contiguous()
         db2 = delta_b.reshape(x2.shape).to(delta.dtype).contiguous() if delta_b is not None else None
         ctx.two = delta_b is not None
-        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype, db2)
+        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype, db2, y=y_buf[0] if y_buf else None)
         ctx.save_for_backward(x_out, mean, rstd)
         ctx.params = (gamma, beta, delta_bias)
+        ctx.delta_from = delta_from
         ctx.delta_dtype = delta.dtype
         ctx.set_materialize_grads(False)
         return x_out.view(x.shape), y.view(x.shape)
@@ -335,7 +342,7 @@ class _AddLayerNorm(torch.autograd.Function):
         if delta_bias is not None and not delta_bias.requires_grad:
             delta_bias = None
         if dy is None and dx_new is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None
         if dy is None:      # only the residual output was used
             dres = dx_new.reshape(x_out.shape).contiguous().float()
             dlp = dres.to(ctx.delta_dtype)
@@ -343,22 +350,43 @@ class _AddLayerNorm(torch.autograd.Function):
             if delta_bias is not None:
                 buf, dc_ret = _grad_buffer(delta_bias)
                 buf.add_(dlp.float().sum(0))
-            return dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret, (dlp.view(dx_new.shape) if ctx.two else None)
+            return (dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret,
+                    (dlp.view(dx_new.shape) if ctx.two else None), None, None)
         dres2 = dx_new.reshape(x_out.shape).contiguous().float() if dx_new is not None else None
         dx, dx_lp, dg, db, dc = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype,
-                                        delta_bias)
+                                        delta_bias, ctx.delta_from)
         shape = dy.shape
         dd = (dx_lp if dx_lp is not None else dx).view(shape)
-        return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None)
+        return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None), None, None
 
 
-def layer_norm(x, ln, out_dtype):
-    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype)
+def _x_slab_for(weight, rows, n, dtype, device):
+    """Stacked-operand slab (see _DeferredWeightGrads) for the producer of the next input of `weight`'s projection, or None."""
+    if weight is None or not (STACKED_ACTIVATIONS and BATCH_DW and torch.is_grad_enabled() and weight.requires_grad):
+        return None
+    return _deferred_dw_for(device).x_slab(weight, rows, n, dtype)
 
 
-def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None, delta_b=None):
-    """-> (x + delta [+ delta_b] [fp32], LayerNorm of it [out_dtype]).  delta_bias, delta_b: see _AddLayerNorm."""
-    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias, delta_b)
+def _pass_of(weight, device):
+    """(weight, index of its projection's latest forward pass) for the producer of that projection's output gradient, or None."""
+    if weight is None or not (STACKED_ACTIVATIONS and BATCH_DW and torch.is_grad_enabled() and weight.requires_grad):
+        return None
+    k = _deferred_dw_for(device).last_pass(weight)
+    return (weight, k) if k is not None else None
+
+
+def layer_norm(x, ln, out_dtype, out_for=None):
+    """out_for: the weight of the projection that reads the result (its stacked dW operand is written in place)."""
+    y_buf = _x_slab_for(out_for, x.numel() // x.shape[-1], x.shape[-1], out_dtype, x.device)
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype, (y_buf,) if y_buf is not None else None)
+
+
+def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None, delta_b=None, out_for=None, delta_from=None):
+    """-> (x + delta [+ delta_b] [fp32], LayerNorm of it [out_dtype]).  delta_bias, delta_b: see _AddLayerNorm.  out_for: as in
+    layer_norm; delta_from: the weight of the projection that produced delta (its output gradient is written into its stack)."""
+    y_buf = _x_slab_for(out_for, x.numel() // x.shape[-1], x.shape[-1], out_dtype, x.device)
+    return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias, delta_b,
+                               (y_buf,) if y_buf is not None else None, _pass_of(delta_from, x.device))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -456,11 +484,62 @@ def _accumulate_matmul(p, a, b):
 BATCH_DW = os.environ.get("BRANCHGAN_BATCH_DW", "1") != "0"
 
 
+# The operands of those batched GEMMs are [layers][rows of every pass][features] stacks.  The first pass over a model copies the
+# layers' saved activations and output gradients into them (bg_stack_rows: 1.1 ms a step at configs[1], 3.6 GB moved); the
+# stacks then stay (per group of weights, `_Stack`), and from the next step on the PRODUCERS write there in the first place:
+# the LayerNorm / attention / GELU kernels get the (layer, pass) slab of the x stack as their output buffer (`out_for=` the
+# weight of the consuming projection), the LayerNorm / attention / GELU backward kernels the slab of the dy stack (`delta_from=`,
+# `qkv_from=`).  flush() copies only what is not at its place.  A slab is handed out again only after the backward pass that read
+# it has flushed (or its autograd node is gone); a saved activation overwritten anyway (retain_graph + another forward) raises in
+# backward.  BRANCHGAN_STACKED_ACTIVATIONS=0: transient stacks, everything copied, as in the first step.
+STACKED_ACTIVATIONS = os.environ.get("BRANCHGAN_STACKED_ACTIVATIONS", "1") != "0"
+STACK_BYTES_CAP = int(float(os.environ.get("BRANCHGAN_STACK_GIB", "48")) * (1 << 30))
+stack_stats = {"copied": 0, "in_place": 0}
+
+
+class _Stack:
+    def __init__(self, weights, rows, n_in, n_out, dtype, device):
+        import weakref
+        self.weights = [weakref.ref(w) for w in weights]
+        self.rows, self.dtype = tuple(rows), dtype
+        self.off = [sum(rows[:i]) for i in range(len(rows))]
+        L, R = len(weights), sum(rows)
+        self.xa = torch.empty((L, R, n_in), dtype=dtype, device=device)
+        self.da = torch.empty((L, R, n_out), dtype=dtype, device=device)
+        self.pinned = torch.cuda.is_current_stream_capturing()      # a recorded graph holds its addresses: never dropped
+        self.tick = 0
+
+    def nbytes(self):
+        return (self.xa.numel() + self.da.numel()) * self.xa.element_size()
+
+    def slab(self, which, l, k, rows, n, dtype):
+        buf = self.xa if which == "x" else self.da
+        if k >= len(self.rows) or self.rows[k] != rows or buf.shape[2] != n or dtype != self.dtype:
+            return None
+        return buf[l, self.off[k]:self.off[k] + rows].data      # .data: a version counter of its own (the slabs of a stack are
+                                                                # written at different times; autograd checks saved tensors by version)
+
+
+class _SlabToken:
+    """Lives in the autograd node of the projection that read a slab; when the node goes without a backward pass the slab is free
+    again."""
+    def __init__(self, owner, wid, k, gen):
+        self.owner, self.wid, self.k, self.gen = owner, wid, k, gen
+
+    def __del__(self):
+        try:
+            self.owner.release(self.wid, self.k, self.gen)
+        except Exception:
+            pass
+
+
 class _DeferredWeightGrads:
     def __init__(self, device):
         self.device = device
         self.pending, self.armed, self.task = [], False, -1
         self.streams = set()
+        self.stacks, self.where, self.tick = {}, {}, 0      # group key -> _Stack; id(weight) -> (_Stack, layer index)
+        self.next_k, self.busy, self.gen = {}, {}, {}       # per weight: forward passes since its last flush; slabs being read
 
     def begin(self):
         task = torch._C._current_graph_task_id()
@@ -478,8 +557,89 @@ class _DeferredWeightGrads:
         self.armed, self.task = True, task
         return True
 
-    def add(self, weight, buf, layout, x2, dy2):
-        self.pending.append((weight, buf, layout, x2, dy2))
+    # ---- slabs -----------------------------------------------------------------------------------------------------------
+    def _slab(self, weight, which, k, rows, n, dtype):
+        ent = self.where.get(id(weight))
+        if ent is None or ent[0].weights[ent[1]]() is not weight:
+            return None
+        st, l = ent
+        t = st.slab(which, l, k, rows, n, dtype)
+        if t is not None:
+            self.tick += 1
+            st.tick = self.tick
+            st.pinned = st.pinned or torch.cuda.is_current_stream_capturing()
+        return t
+
+    def x_slab(self, weight, rows, n, dtype):
+        """Output buffer for the producer of the NEXT forward input of `weight`'s projection (None: allocate as usual)."""
+        k = self.next_k.get(id(weight), 0)
+        if k in self.busy.get(id(weight), ()):
+            return None
+        return self._slab(weight, "x", k, rows, n, dtype)
+
+    def dy_slab(self, weight, k, rows, n, dtype):
+        return self._slab(weight, "dy", k, rows, n, dtype) if k is not None else None
+
+    def forward_pass(self, weight, x2):
+        """The projection of `weight` runs forward on x2 (grad mode): -> (pass index, token or None)."""
+        wid = id(weight)
+        k = self.next_k.get(wid, 0)
+        self.next_k[wid] = k + 1
+        t = self._slab(weight, "x", k, x2.shape[0], x2.shape[1], x2.dtype) if k not in self.busy.get(wid, ()) else None
+        if t is None or t.data_ptr() != x2.data_ptr() or x2.stride() != t.stride():
+            return k, None
+        self.busy.setdefault(wid, set()).add(k)
+        g = self.gen[(wid, k)] = self.gen.get((wid, k), 0) + 1
+        return k, _SlabToken(self, wid, k, g)
+
+    def last_pass(self, weight):
+        k = self.next_k.get(id(weight), 0) - 1
+        return k if k >= 0 else None
+
+    def current(self, token):
+        return self.gen.get((token.wid, token.k)) == token.gen
+
+    def release(self, wid, k, gen=None):
+        if gen is not None and self.gen.get((wid, k)) != gen:
+            return
+        b = self.busy.get(wid)
+        if b is not None and k in b:
+            b.discard(k)
+            if not b:
+                self.next_k[wid] = 0
+
+    def _stack_for(self, key, members, rows, n_in, n_out, dtype):
+        weights = [m[3] for m in members]
+        key = key + tuple(id(w) for w in weights)
+        st = self.stacks.get(key)
+        # slabs still being read by a forward pass that is not part of this flush: leave every kept stack alone
+        held = any(self.busy.get(id(w), set()) - ks for w, ks in zip(weights, (m[4] for m in members)))
+        if st is not None and all(r() is w for r, w in zip(st.weights, weights)) and not held:
+            for l, w in enumerate(weights):
+                self.where[id(w)] = (st, l)
+            return st
+        st = _Stack(weights, rows, n_in, n_out, dtype, self.device)
+        if not STACKED_ACTIVATIONS or held:
+            return st
+        total = st.nbytes() + sum(o.nbytes() for o in self.stacks.values())
+        for okey, o in sorted(self.stacks.items(), key=lambda kv: kv[1].tick):
+            if total <= STACK_BYTES_CAP:
+                break
+            if not o.pinned:
+                total -= o.nbytes()
+                del self.stacks[okey]
+                for wid in [wid for wid, ent in self.where.items() if ent[0] is o]:
+                    del self.where[wid]
+        if total > STACK_BYTES_CAP:
+            return st                                   # transient: nobody learns where it is
+        self.stacks[key] = st
+        for l, w in enumerate(weights):
+            self.where[id(w)] = (st, l)
+        return st
+
+    # ---- the batched GEMMs ---------------------------------------------------------------------------------------------
+    def add(self, weight, buf, layout, x2, dy2, k=None):
+        self.pending.append((weight, buf, layout, x2, dy2, k))
         self.streams.add(torch.cuda.current_stream(self.device))
 
     def flush(self):
@@ -494,15 +654,17 @@ class _DeferredWeightGrads:
                 if st != cur:
                     cur.wait_stream(st)
             per_weight = {}
-            for weight, buf, layout, x2, dy2 in pending:
-                per_weight.setdefault(id(weight), (buf, layout, [], []))
-                per_weight[id(weight)][2].append(x2)
-                per_weight[id(weight)][3].append(dy2)
+            for weight, buf, layout, x2, dy2, k in pending:
+                passes = per_weight.setdefault(id(weight), (buf, layout, [], weight))[2]
+                passes.append((len(passes) if k is None else k, x2, dy2))
             groups = {}
-            for buf, layout, xs, dys in per_weight.values():
+            for buf, layout, passes, weight in per_weight.values():
+                passes.sort(key=lambda t: t[0])               # forward order: the order the stacks are laid out in
+                xs, dys = [t[1] for t in passes], [t[2] for t in passes]
                 key = (layout, xs[0].dtype, tuple(buf.shape), tuple(x.shape[0] for x in xs), xs[0].shape[1], dys[0].shape[1])
-                groups.setdefault(key, []).append((buf, xs, dys))
-            for (layout, dtype, wshape, rows, n_in, n_out), members in groups.items():
+                groups.setdefault(key, []).append((buf, xs, dys, weight, {t[0] for t in passes}))
+            for key, members in groups.items():
+                layout, dtype, wshape, rows, n_in, n_out = key
                 members.sort(key=lambda m: m[0].data_ptr())
                 stride = None
                 if len(members) > 1 and dtype != torch.float32 and _mm_out_dtype:
@@ -513,20 +675,26 @@ class _DeferredWeightGrads:
                             and all(m[0].untyped_storage().data_ptr() == members[0][0].untyped_storage().data_ptr() for m in members):
                         stride = step // 4
                 if stride is None:
-                    for buf, xs, dys in members:
+                    for buf, xs, dys, _, _ in members:
                         for x2, dy2 in zip(xs, dys):
                             _accumulate_into(buf, x2.t(), dy2) if layout == "io" else _accumulate_into(buf, dy2.t(), x2)
                     continue
                 L, R = len(members), sum(rows)
-                xa = torch.empty((L, R, n_in), dtype=dtype, device=self.device)
-                da = torch.empty((L, R, n_out), dtype=dtype, device=self.device)
-                _stack_rows([x for _, xs, _ in members for x in xs], xa.view(L * R, n_in),
-                            [d_ for _, _, dys in members for d_ in dys], da.view(L * R, n_out))
+                st = self._stack_for(key, members, rows, n_in, n_out, dtype)
+                xa, da = st.xa, st.da
+                _stack_rows([x for _, xs, _, _, _ in members for x in xs], xa.view(L * R, n_in),
+                            [d_ for _, _, dys, _, _ in members for d_ in dys], da.view(L * R, n_out))
                 out = members[0][0].as_strided((L,) + wshape, (stride, wshape[1], 1))
                 if layout == "io":
                     torch.baddbmm(out, xa.transpose(1, 2), da, out_dtype=torch.float32, out=out)
                 else:
                     torch.baddbmm(out, da.transpose(1, 2), xa, out_dtype=torch.float32, out=out)
+            for weight, _, _, _, _, k in pending:
+                if k is not None:
+                    self.release(id(weight), k)
+            for wid in {id(p_[0]) for p_ in pending}:
+                if not self.busy.get(wid):
+                    self.next_k[wid] = 0
 
 
 def _stack_rows(xs, xa, dys, da):
@@ -538,11 +706,24 @@ def _stack_rows(xs, xa, dys, da):
             es = t.element_size()
             if t.stride(1) != 1 or row_bytes % 16 or (t.stride(0) * es) % 16 or t.data_ptr() % 16 or (dst.data_ptr() + off) % 16:
                 ok = False
-            descs.append((t.data_ptr(), dst.data_ptr() + off, t.shape[0], row_bytes, t.stride(0) * es))
+            if t.data_ptr() == dst.data_ptr() + off and t.stride(1) == 1 and t.stride(0) * es == row_bytes:
+                stack_stats["in_place"] += 1            # its producer wrote it here (a slab of a _Stack)
+            else:
+                stack_stats["copied"] += 1
+                descs.append((t.data_ptr(), dst.data_ptr() + off, t.shape[0], row_bytes, t.stride(0) * es))
             off += t.shape[0] * row_bytes
     if not ok:
-        torch.cat(xs, out=xa)
-        torch.cat(dys, out=da)
+        # (sources that are slabs of the destination are copied onto themselves row by row: cat handles the overlap-free case only)
+        off = 0
+        for srcs, dst in ((xs, xa), (dys, da)):
+            off = 0
+            for t in srcs:
+                part = dst[off:off + t.shape[0]]
+                if part.data_ptr() != t.data_ptr() or part.stride() != t.stride():
+                    part.copy_(t)
+                off += t.shape[0]
+        return
+    if not descs:
         return
     arr = (C.StackDesc * len(descs))()
     for d, (src, dst, rows, rb, st) in zip(arr, descs):
@@ -574,17 +755,24 @@ class _Linear(torch.autograd.Function):
     """y = act(x @ W + b).  layout 'io': W is (in, out) (GPT-2 Conv1D); 'oi': (out, in) (nn.Linear)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, layout, act, dtype, bias_grad):
+    def forward(ctx, x, weight, bias, layout, act, dtype, bias_grad, out_for=None):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.dtype != dtype:
             x2 = x2.to(dtype)
         w = lowp(weight, dtype)
         wm = w if layout == "io" else w.t()
         pre = torch.addmm(lowp(bias, dtype), x2, wm) if bias is not None else torch.mm(x2, wm)
+        ctx.pass_k = ctx.slab = None
+        if out_for is not None:             # grad mode (linear() checked): this pass's place in the stacked dW operands
+            ctx.pass_k, ctx.slab = _deferred_dw_for(x2.device).forward_pass(weight, x2)
         if act is None:
             y = pre
         else:
-            y = F.gelu(pre, approximate="tanh" if act == "gelu_tanh" else "none")
+            y = out_for[0] if out_for else None         # the activation is the next projection's input: into its x stack
+            if y is not None:
+                torch.ops.aten.gelu.out(pre, approximate="tanh" if act == "gelu_tanh" else "none", out=y)
+            else:
+                y = F.gelu(pre, approximate="tanh" if act == "gelu_tanh" else "none")
         ctx.save_for_backward(x2, pre if act is not None else None)
         ctx.meta = (weight, bias if bias_grad else None, layout, act, dtype, x.shape)
         return y.view(*x.shape[:-1], y.shape[-1])
@@ -593,6 +781,10 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x2, pre = ctx.saved_tensors
         weight, bias, layout, act, dtype, in_shape = ctx.meta
+        if ctx.slab is not None and not _deferred_dw_for(x2.device).current(ctx.slab):
+            raise RuntimeError("branchgan.fused: a saved activation in the stacked dW operands was overwritten by a later forward "
+                               "pass before this backward ran (retain_graph with another forward in between?); "
+                               "set BRANCHGAN_STACKED_ACTIVATIONS=0")
         dy2 = dy.reshape(-1, dy.shape[-1])
         if dy2.dtype != dtype:
             dy2 = dy2.to(dtype)
@@ -604,7 +796,9 @@ class _Linear(torch.autograd.Function):
             lib = C.lib()
             if act is not None:
                 dy2 = dy2.contiguous()
-                dpre = torch.empty_like(pre)
+                dpre = _deferred_dw_for(dy2.device).dy_slab(weight, ctx.pass_k, rows, n_out, pre.dtype) if BATCH_DW else None
+                if dpre is None:
+                    dpre = torch.empty_like(pre)
             else:
                 dpre = None
             db = None                       # no bias (or not ours to differentiate): the partial sums are simply never reduced
@@ -634,7 +828,7 @@ class _Linear(torch.autograd.Function):
             if ret is None:                              # the gradient lives in p.grad (the arena): the GEMM can wait
                 later = _deferred_dw_for(dy2.device)
                 if later.begin():
-                    later.add(weight, buf, layout, x2, dy2)
+                    later.add(weight, buf, layout, x2, dy2, ctx.pass_k)
                 else:
                     later = None
             if later is None:
@@ -642,12 +836,20 @@ class _Linear(torch.autograd.Function):
                 dw_ret = ret
         else:
             dw_ret = _accumulate_matmul(weight, x2.t(), dy2) if layout == "io" else _accumulate_matmul(weight, dy2.t(), x2)
-        return dx, dw_ret, db_ret, None, None, None, None
+        return dx, dw_ret, db_ret, None, None, None, None, None
 
 
-def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True):
-    """bias_grad=False: the bias is added in forward but its gradient is somebody else's job (add_layer_norm(delta_bias=))."""
-    return _Linear.apply(x, weight, bias, layout, act, dtype, bias_grad)
+def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True, out_for=None):
+    """bias_grad=False: the bias is added in forward but its gradient is somebody else's job (add_layer_norm(delta_bias=)).
+    out_for (with act): the weight of the projection that reads the activation (see layer_norm)."""
+    track = None
+    if STACKED_ACTIVATIONS and BATCH_DW and torch.is_grad_enabled() and weight.requires_grad:
+        y_buf = None
+        if act is not None and out_for is not None:
+            n_out = weight.shape[1] if layout == "io" else weight.shape[0]
+            y_buf = _x_slab_for(out_for, x.numel() // x.shape[-1], n_out, dtype, x.device)
+        track = (y_buf,) if y_buf is not None else ()
+    return _Linear.apply(x, weight, bias, layout, act, dtype, bias_grad, track)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -683,7 +885,8 @@ class _MergedTreeAttention(torch.autograd.Function):
         B, T, _, H, Dh = qkv.shape
         S, N = spec["n_text"], spec["n_query_nodes"]
         K = (T - S) // N
-        att = torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
+        att = spec["att_buf"].view(B, T, H, Dh) if spec.get("att_buf") is not None else \
+            torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
         lse_r = torch.empty((B, H, 1, S), dtype=torch.float32, device=qkv.device)
         lse_t = torch.empty((B, H, N, K), dtype=torch.float32, device=qkv.device)
         kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
@@ -695,6 +898,7 @@ class _MergedTreeAttention(torch.autograd.Function):
                        _heads_first(att[:, S:], N, K), lse_t)
         ctx.save_for_backward(qkv, att, lse_r, lse_t, spec["ctx_len"])
         ctx.meta = (S, N, K, spec["scale"], spec["paths"])
+        ctx.qkv_from = spec.get("qkv_from")
         ctx.set_materialize_grads(False)
         return att.view(B, T, H * Dh), kview, vview
 
@@ -703,7 +907,7 @@ class _MergedTreeAttention(torch.autograd.Function):
         qkv, att, lse_r, lse_t, ctx_len = ctx.saved_tensors
         S, N, K, scale, paths = ctx.meta
         B, T, _, H, Dh = qkv.shape
-        dqkv = torch.empty_like(qkv)
+        dqkv = _dqkv_buffer(qkv, ctx.qkv_from)
         if datt is None:
             datt = torch.zeros((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
         do = datt.reshape(B, T, H, Dh).to(qkv.dtype).contiguous()
@@ -739,7 +943,8 @@ class _PackedAttention(torch.autograd.Function):
         root = k_text is None
         NQ = 1 if root else spec["n_query_nodes"]
         K = T // NQ
-        att = torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
+        att = spec["att_buf"].view(B, T, H, Dh) if spec.get("att_buf") is not None else \
+            torch.empty((B, T, H, Dh), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=qkv.device)
         q5 = qkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)          # (B,H,NQ,K,Dh) strided view
         o5 = att.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
@@ -764,6 +969,7 @@ class _PackedAttention(torch.autograd.Function):
         ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
         ctx.save_for_backward(qkv, att, lse, ctx_len, path, path_len, *([] if root else [kt, vt]), *anc_k, *anc_v)
         ctx.meta = (root, NQ, K, n_anc, spec["scale"], max_path)
+        ctx.qkv_from = spec.get("qkv_from")
         ctx.set_materialize_grads(False)
         return att.view(B, T, E), kview, vview
 
@@ -775,7 +981,7 @@ class _PackedAttention(torch.autograd.Function):
         rest = list(saved[6:])
         B, T, _, H, Dh = qkv.shape
         dev, dt = qkv.device, qkv.dtype
-        dqkv = torch.empty_like(qkv)
+        dqkv = _dqkv_buffer(qkv, ctx.qkv_from)
         q5 = qkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
         o5 = att.unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
         dq5 = dqkv[:, :, 0].unflatten(1, (NQ, K)).permute(0, 3, 1, 2, 4)
@@ -830,16 +1036,29 @@ class _PackedAttention(torch.autograd.Function):
         return (dqkv, dkt, dvt, None, *d_anc_k, *d_anc_v)
 
 
-def packed_attention(qkv, lp, scale):
-    """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views)."""
+def _dqkv_buffer(qkv, qkv_from):
+    """The packed dq / dk / dv buffer = the output gradient of the QKV projection: in that projection's dy stack when it has one."""
+    t = None
+    if qkv_from is not None and qkv.is_contiguous():
+        B, T = qkv.shape[:2]
+        t = _deferred_dw_for(qkv.device).dy_slab(qkv_from[0], qkv_from[1], B * T, qkv[0, 0].numel(), qkv.dtype)
+    return t.view(qkv.shape) if t is not None else torch.empty_like(qkv)
+
+
+def packed_attention(qkv, lp, scale, out_for=None, qkv_from=None):
+    """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views).
+    out_for: the weight of the projection that reads att; qkv_from: the weight of the projection that produced qkv (see layer_norm /
+    add_layer_norm)."""
+    B, T, _, H, Dh = qkv.shape
+    extra = {"att_buf": _x_slab_for(out_for, B * T, H * Dh, qkv.dtype, qkv.device), "qkv_from": _pass_of(qkv_from, qkv.device)}
     if lp is None:
-        att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale)})
+        att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale), **extra})
     elif getattr(lp, "merged_text", 0):
         spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes,
-                "n_text": lp.merged_text}
+                "n_text": lp.merged_text, **extra}
         att, k, v = _MergedTreeAttention.apply(qkv, spec)
     else:
-        spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes}
+        spec = {"scale": float(scale), "ctx_len": lp.ctx_len, "paths": lp.paths, "n_query_nodes": lp.n_query_nodes, **extra}
         anc_k = [a[0] for a in lp.ancestors]
         anc_v = [a[1] for a in lp.ancestors]
         att, k, v = _PackedAttention.apply(qkv, lp.text[0], lp.text[1], spec, *anc_k, *anc_v)

@@ -92,6 +92,18 @@ def _check_rules(rules):
             raise NotImplementedError("GraphedTrainStep: 'noise_level' (Dirichlet noise from torch's global generator) cannot be captured")
 
 
+def _settle_collectives():
+    """ProcessGroupNCCL's watchdog thread polls the end events of the collectives it has not retired yet (every 100 ms) and aborts
+    the process when such a query fails - and on ROCm 7.2 hipEventQuery FAILS for an event whose stream is part of a capture in
+    progress on another thread (benchmarks/probes/event_query_during_capture.py).  The warm-up steps' collectives are finished
+    when this is called (device synchronised); give the watchdog time to see that, so that it has nothing to poll while the
+    captures run (they enqueue no collective)."""
+    import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and torch.cuda.is_available() and "nccl" in str(dist.get_backend()):
+        time.sleep(0.35)
+
+
 class GraphedTrainStep:
     """`warmup` eager steps lay out the arenas, caches and workspaces; they run on `example_ids` and, unless
     restore_after_warmup=False, parameters, optimizer state (moments, step counts) and LR schedulers are put back to what
@@ -162,6 +174,7 @@ class GraphedTrainStep:
                                        "outputs of an earlier eager step): drop those references before building the graphed step")
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            _settle_collectives()
             timing, ops.TIMING = ops.TIMING, None              # events cannot be recorded inside a capture
             # three graphs: [generator forward], [discriminator forward + losses + generator backward], [discriminator backward];
             # see step() for what runs between them.

@@ -254,20 +254,22 @@ class GPTNeoXLayer(nn.Module):
         previous block's update `delta` (None for the first block; a pair (attention, MLP) after a parallel-residual block,
         added in the LayerNorm kernel); returns (x + delta, this block's update, present).
         Parallel residual: both LayerNorms read x + delta, the update is attention + MLP."""
+        qkv_w, up_w, down_w = self.attention.query_key_value.weight, self.mlp.dense_h_to_4h.weight, self.mlp.dense_4h_to_h.weight
         if delta is None:
-            x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype)
+            x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype, out_for=qkv_w)
         elif isinstance(delta, tuple):
-            x1, h1 = fused.add_layer_norm(x, delta[0], self.input_layernorm, dtype, delta_b=delta[1])
+            x1, h1 = fused.add_layer_norm(x, delta[0], self.input_layernorm, dtype, delta_b=delta[1], out_for=qkv_w)
         else:
-            x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype)
+            x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype, out_for=qkv_w)
         a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
         if self.use_parallel_residual:
-            h2 = fused.layer_norm(x1, self.post_attention_layernorm, dtype)
-            g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
-            m = fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype)
+            h2 = fused.layer_norm(x1, self.post_attention_layernorm, dtype, out_for=up_w)
+            g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
+            m = fused.linear(g, down_w, self.mlp.dense_4h_to_h.bias, "oi", dtype)
             return x1, (a, m), present
-        x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias)
-        g = fused.linear(h2, self.mlp.dense_h_to_4h.weight, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu")
+        x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias, out_for=up_w,
+                                      delta_from=self.attention.dense.weight)
+        g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
         return x2, fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype), present
 
 
@@ -523,21 +525,23 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
-    def fused_forward(self, x, delta, delta_bias, dtype, lp):
+    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None):
         """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
-        block's MLP output, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel."""
+        block's MLP output - of the projection with weight delta_from -, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel."""
         at = self.attn
         B, T, _ = x.shape
+        # out_for / delta_from / qkv_from name the projection on the other side of a tensor: producers then write the stacked
+        # operands of the batched weight-gradient GEMMs in place (fused._DeferredWeightGrads)
         if delta is None:
-            x1, h1 = x, fused.layer_norm(x, self.ln_1, dtype)
+            x1, h1 = x, fused.layer_norm(x, self.ln_1, dtype, out_for=at.c_attn.weight)
         else:
-            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias)
+            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias, out_for=at.c_attn.weight, delta_from=delta_from)
         qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
-        a, present = fused.packed_attention(qkv, lp, at._scale())
+        a, present = fused.packed_attention(qkv, lp, at._scale(), out_for=at.c_proj.weight, qkv_from=at.c_attn.weight)
         # the two projections that feed a residual add leave their bias gradient to the LayerNorm backward that follows
         a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
-        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias)
-        g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh")
+        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight)
+        g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh", out_for=self.mlp.c_proj.weight)
         delta = fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype, bias_grad=False)
         return x2, delta, self.mlp.c_proj.bias, present
 
@@ -582,11 +586,13 @@ class NonResidualGPT2LMHeadModel(_LMBase):
             fused.prepare_weights(self, dtype)
             with torch.autocast("cuda", enabled=False):
                 x, delta, delta_bias, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, None, []
+                delta_from = None
                 for i, block in enumerate(tr.h):
                     x, delta, delta_bias, present = block.fused_forward(x, delta, delta_bias, dtype,
-                                                                        _layer_past(textualPast, i) if branch else None)
+                                                                        _layer_past(textualPast, i) if branch else None, delta_from)
+                    delta_from = block.mlp.c_proj.weight
                     presents.append(present)
-                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias)
+                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias, delta_from=delta_from)
                 head = self.lm_head if returnLmLogits else self.valueHead
                 logits = fused.linear(y, head.weight, None, "oi", dtype)
             return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,

@@ -363,3 +363,81 @@ def test_stack_rows_matches_cat():
     dout = torch.zeros(5, 6, device="cuda")
     fused._stack_rows(odd, out, odd, dout)
     assert torch.equal(out, odd[0]) and torch.equal(dout, odd[0])
+
+
+def test_stacked_activations_written_in_place(monkeypatch):
+    """Once a model's batched weight-gradient GEMMs have run, their stacked operands stay and the producers (LayerNorm, attention,
+    GELU forward; LayerNorm, attention, GELU backward) write them in place: nothing is copied any more, and the gradients are
+    bit-identical to the all-copied form.  Root pass + tree pass share the weights (two passes per stack)."""
+    from branchgan import fused, models, training
+    model = _gpt2(hidden=128, heads=4, layers=3)
+    B, S, K = 2, 40, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ids = torch.randint(0, 97, (B, S), device="cuda", generator=g)
+    t_ids = torch.randint(0, 97, (B, 3 * K), device="cuda", generator=g)
+    sparse = torch.tensor([3, 9, 20, 31], device="cuda")
+    ctx_len = (sparse + 1).to(torch.int32)
+    depths = torch.tensor([1, 1, 2], device="cuda")
+    pos3 = (sparse.unsqueeze(0) + depths.unsqueeze(1)).reshape(1, 3 * K).expand(B, -1).to(torch.int32)
+    L = len(model.transformer.h)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(input_ids=ids, use_cache=True)
+            text = [out.past_key_values[l] for l in range(L)]
+            past = models.BranchPast(text=text, ancestors=[[] for _ in range(L)], ctx_len=ctx_len, paths=[[0], [1], [0, 2]], n_query_nodes=3)
+            o3 = model(input_ids=t_ids, position_ids=pos3, textualPast=past, use_cache=True)
+        ((out.logits.float() ** 2).mean() + (o3.logits.float() ** 2).mean() * 2).backward()
+
+    step()                                           # gradients exist; the fp32-output GEMM form is probed
+    arena = training.GradArena(model)
+    arena._build()                                   # the layers' gradients at one constant stride: the GEMMs batch from here on
+
+    def grads(stacked):
+        monkeypatch.setattr(fused, "STACKED_ACTIVATIONS", stacked)
+        arena.zero()
+        fused.stack_stats.update(copied=0, in_place=0)
+        step()
+        torch.cuda.synchronize()
+        return arena.arena.clone(), dict(fused.stack_stats)
+
+    ref, s0 = grads(False)
+    assert s0["in_place"] == 0 and s0["copied"] == 4 * 2 * 2 * L          # 4 weight kinds x (x, dy) x 2 passes x layers
+    first, s1 = grads(True)                          # lays the stacks down (still copies)
+    second, s2 = grads(True)
+    third, s3 = grads(True)
+    assert s1["copied"] == s0["copied"]
+    assert s2 == {"copied": 0, "in_place": s0["copied"]} and s3 == s2, (s2, s3)
+    assert float(ref.abs().sum()) > 0
+    # the stacks hold the passes in forward order, the all-copied form in the order the backward pass reached them: the same
+    # products summed in another order
+    assert torch.allclose(first, ref, atol=1e-5, rtol=1e-4)
+    ref = first
+    for got in (second, third):
+        assert torch.equal(got, ref)
+    # a forward pass whose backward never runs does not keep the slabs: its autograd nodes go, the slabs are free again
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lost = model(input_ids=ids, use_cache=True).logits
+    del lost
+    again, s4 = grads(True)
+    assert s4 == s2 and torch.equal(again, ref)
+    # ... and while such a pass is alive the next one simply allocates as before (nothing is overwritten)
+    def root_only():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return (model(input_ids=ids.flip(1), use_cache=True).logits.float() ** 2).mean()
+
+    arena.zero()
+    root_only().backward()
+    alone = arena.arena.clone()
+    grads(True)
+    grads(True)                                      # two-pass layout again, slabs in use
+    held = root_only()                               # sits in the slabs of pass 0 ...
+    other, s5 = grads(True)                          # ... while a whole step runs: it must neither use nor overwrite them
+    assert torch.equal(other, ref) and s5["copied"] > 0
+    arena.zero()
+    held.backward()
+    assert torch.equal(arena.arena, alone)
+    del held
+    relaid, s6 = grads(True)                       # the late backward pass laid out stacks of its own: back to the two-pass layout
+    last, s7 = grads(True)
+    assert torch.equal(relaid, ref) and s7 == s2 and torch.equal(last, ref)
