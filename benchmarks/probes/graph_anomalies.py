@@ -146,9 +146,7 @@ def unfused():
         gs.static_ids.copy_(data[1])
         g_opt.arena.zero()
         d_opt.arena.zero()
-        gs.graph_g.replay()
-        gs.graph.replay()
-        gs.graph_d.replay()
+        gs.replay_graphs()
         torch.cuda.synchronize()
         for tag, opt in (("G", g_opt), ("D", d_opt)):
             a = opt.arena.arena.clone()

@@ -30,6 +30,7 @@ ACCUMULATE_IN_PLACE = True
 # BRANCHGAN_FUSED=0 switches the models back to the module-by-module path (A/B runs, debugging)
 ENABLED = os.environ.get("BRANCHGAN_FUSED", "1") != "0"
 
+module_path_forwards = 0       # model forwards that did NOT take this path (models._fused_eligible)
 _cast_cache = {}
 _capture_epoch = 0
 _step_epoch = 0
@@ -153,11 +154,20 @@ def _grad_buffer(p):
 
 
 _ws = {}
+# Work captured into graphs that are REPLAYED side by side (graphs.py: the discriminator's backward beside the generator's) is
+# captured on one stream: its scratch is told apart by the lane the capture declares.
+_lane = 0
+
+
+def set_lane(lane):
+    global _lane
+    previous, _lane = _lane, lane
+    return previous
 
 
 def _workspace(nbytes, device):
-    """Grow-only scratch per (device, stream): kernels of two streams may run at the same time."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """Grow-only scratch per (device, stream, lane): kernels of two streams may run at the same time."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, _lane)
     ws = _ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 4 << 20), dtype=torch.uint8, device=device)
@@ -241,9 +251,9 @@ _deferred = {}
 
 
 def _deferred_for(device):
-    d = _deferred.get(device)
+    d = _deferred.get((device, _lane))
     if d is None:
-        d = _deferred[device] = _DeferredReductions(device)
+        d = _deferred[(device, _lane)] = _DeferredReductions(device)
     return d
 
 

@@ -92,6 +92,12 @@ def _check_rules(rules):
             raise NotImplementedError("GraphedTrainStep: 'noise_level' (Dirichlet noise from torch's global generator) cannot be captured")
 
 
+def _fresh_blas_workspaces():
+    """Drops torch's per-(handle, stream) rocBLAS / hipBLASLt workspaces: the next GEMM allocates a new one - inside a capture, from
+    that capture's memory pool, where it stays for the graph's lifetime."""
+    torch._C._cuda_clearCublasWorkspaces()
+
+
 def _settle_collectives():
     """ProcessGroupNCCL's watchdog thread polls the end events of the collectives it has not retired yet (every 100 ms) and aborts
     the process when such a query fails - and on ROCm 7.2 hipEventQuery FAILS for an event whose stream is part of a capture in
@@ -127,6 +133,8 @@ class GraphedTrainStep:
         self._sync = _sync_after_replay()
         self._defer_d = _multi_rank() if os.environ.get("BRANCHGAN_DEFER_D") is None else os.environ["BRANCHGAN_DEFER_D"] == "1"
         self._pending_d = None
+        # one rank: the discriminator's backward graph is replayed on a second stream BESIDE the generator's (see _step)
+        self._overlap = (not self._defer_d) if os.environ.get("BRANCHGAN_OVERLAP_BWD") is None else os.environ["BRANCHGAN_OVERLAP_BWD"] == "1"
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
         # exponential noise of the race techniques: persistent tensors, one per sampling call of a step, refreshed before a replay
         self._noise, self._noise_cursor, self._user_noise = [], 0, model.noise_fn
@@ -139,6 +147,11 @@ class GraphedTrainStep:
             side = torch.cuda.Stream(device=dev)
             model.__dict__["_graph_stream"] = side
         self.stream = side
+        aux = model.__dict__.get("_graph_aux_stream")
+        if aux is None or aux.device != dev:
+            aux = torch.cuda.Stream(device=dev)
+            model.__dict__["_graph_aux_stream"] = aux
+        self.aux = aux
         if os.environ.get("BRANCHGAN_DEBUG_STREAMS"):
             print(f"[streams] side {side.cuda_stream:#x}  g_opt.stream {getattr(getattr(generatorOptim, 'stream', None), 'cuda_stream', 0):#x}  "
                   f"d_opt.stream {getattr(getattr(discriminatorOptim, 'stream', None), 'cuda_stream', 0):#x}  current {torch.cuda.current_stream().cuda_stream:#x}", flush=True)
@@ -147,6 +160,7 @@ class GraphedTrainStep:
         if warmup < 1:
             raise ValueError("GraphedTrainStep: at least one warm-up step (it lays out the arenas, workspaces and noise tensors)")
         saved = self._snapshot() if restore_after_warmup else None
+        module_forwards = fused.module_path_forwards
         model.noise_fn = self._static_noise
         try:
             import warnings
@@ -179,26 +193,59 @@ class GraphedTrainStep:
             # three graphs: [generator forward], [discriminator forward + losses + generator backward], [discriminator backward];
             # see step() for what runs between them.
             self.graph_g, self.graph, self.graph_d = new_graph(), new_graph(), new_graph()
+            self.graph_gb = new_graph() if self._overlap else None
             fused.begin_capture()                              # weight copies cast before the capture must be re-cast inside it
             # ONE stream for the warm-up and all three captures: autograd runs every AccumulateGrad node on the stream it was created
             # on, and a node created while one graph is captured must not end up on another graph's stream.  (A node that lives on the
             # DEFAULT stream is worse: autograd then pulls the null stream into the capture and ROCm 7.2's hipStreamEndCapture
             # segfaults walking the capture's streams - benchmarks/probes/graph_anomalies.py segv-nonleaf.)
             self._noise_cursor = 0
+            if self._overlap:
+                _fresh_blas_workspaces()
             with torch.cuda.graph(self.graph_g, stream=side, capture_error_mode="thread_local"):   # collective backends run helper threads
                 with self._autocast():
                     self.gen_state = self.model._generatorForward(self.static_ids, self.conf)
             # the sampled branch tokens of every tree node, (B, K) each, valid after a replay of graph_g (the second graph clears the tree)
             self.sampled_ids = [n.ids for n in self.gen_state[0].getSubNodes()]
-            with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
-                self.losses = self._forward(self.gen_state)
-                self.losses[1][self.g_opt.lossKey].backward()
-            with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
-                self.losses[0][self.d_opt.lossKey].backward()
+            if not self._overlap:
+                with torch.cuda.graph(self.graph, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
+                    self.losses = self._forward(self.gen_state)
+                    self.losses[1][self.g_opt.lossKey].backward()
+                with torch.cuda.graph(self.graph_d, pool=self.graph_g.pool(), stream=side, capture_error_mode="thread_local"):
+                    self.losses[0][self.d_opt.lossKey].backward()
+            else:
+                # Four graphs; graph_d runs BESIDE graph_gb, so the two must share nothing they write:
+                #  * memory pools: a pool hands blocks freed by one capture to the next (which is right when the graphs replay one
+                #    after the other) - here every graph gets its own, so no graph's temporaries sit in blocks another one uses;
+                #  * GEMM workspaces: torch keeps one per (handle, stream) and all captures run on `side`; nearly every hipBLASLt
+                #    kernel here is a stream-K one that keeps partial tiles there - dropped before each capture, so that each graph
+                #    allocates its own (from its own pool);
+                #  * this library's scratch (column-reduction partials, workspaces): fused.set_lane.
+                _fresh_blas_workspaces()
+                with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                    self.losses = self._forward(self.gen_state)
+                _fresh_blas_workspaces()
+                with torch.cuda.graph(self.graph_gb, stream=side, capture_error_mode="thread_local"):
+                    self.losses[1][self.g_opt.lossKey].backward()
+                _fresh_blas_workspaces()
+                lane = fused.set_lane(1)
+                try:
+                    with torch.cuda.graph(self.graph_d, stream=side, capture_error_mode="thread_local"):
+                        self.losses[0][self.d_opt.lossKey].backward()
+                finally:
+                    fused.set_lane(lane)
+                _fresh_blas_workspaces()
             ops.TIMING = timing
         finally:
             model.noise_fn = self._user_noise
-        self.census = [finalize_graph(g) for g in (self.graph_g, self.graph, self.graph_d)]     # memset nodes -> fill kernels
+        graphs = [g for g in (self.graph_g, self.graph, self.graph_gb, self.graph_d) if g is not None]
+        self.census = [finalize_graph(g) for g in graphs]     # memset nodes -> fill kernels
+        # Side by side only what this library accounts for.  The module-by-module path reduces bias gradients with ATen's
+        # multi-block reductions (they are what brings memset nodes into a capture); replayed beside each other, the two backward
+        # graphs then disagree with the eager step in a few elements of those gradients (benchmarks/probes/overlap_mismatch.py:
+        # only *.bias, both models), while the fused path is bit-identical to it.  Such a step replays its four graphs in turn.
+        self._side_by_side = self._overlap and fused.module_path_forwards == module_forwards and \
+            all(c[2] == 0 for c in self.census[2:])
         # the capture ran the backward once for real bookkeeping purposes only: clear what it accumulated
         self.g_opt.arena.zero()
         self.d_opt.arena.zero()
@@ -321,6 +368,8 @@ class GraphedTrainStep:
         self.static_ids.copy_(inputIDs, non_blocking=True)
         self._refresh_sparse(inputIDs)
         self._refresh_noise()
+        if self._overlap:
+            return self._step_overlapped(stepCounter, updateGen, updateDisc)
         self.graph_g.replay()                              # generator forward
         self._finish_pending()                             # D's all-reduce of the last step is done by now: its Adam step
         self.graph.replay()                                # discriminator forward + losses + generator backward
@@ -342,6 +391,51 @@ class GraphedTrainStep:
             self._pending_d = d_stepped
         else:
             self.d_opt.finish(d_stepped)
+        return d, g
+
+    def replay_graphs(self):
+        """The captured graphs in the order (and on the streams) a step replays them, without reductions and optimizer steps."""
+        self.graph_g.replay()
+        self.graph.replay()
+        if not self._side_by_side:
+            if self.graph_gb is not None:
+                self.graph_gb.replay()
+            self.graph_d.replay()
+            return
+        main = torch.cuda.current_stream()
+        self.aux.wait_stream(main)
+        with torch.cuda.stream(self.aux):
+            self.graph_d.replay()
+        self.graph_gb.replay()
+        main.wait_stream(self.aux)
+
+    def _step_overlapped(self, stepCounter, updateGen, updateDisc):
+        """One rank.  The generator's backward is ~450 launches on 256-row batches (one tree level at a time) that leave most of
+        the chip idle; the discriminator's backward does not depend on it.  graph_d is replayed on a second stream beside
+        graph_gb (measured at configs[1]: 3.15 ms + 4.4 ms one after the other, ~6 ms side by side); both optimizer steps follow
+        on the main stream once the streams have joined, so nothing outlives the call."""
+        main = torch.cuda.current_stream()
+        self.graph_g.replay()                              # generator forward
+        self.graph.replay()                                # discriminator forward + losses
+        if self._side_by_side:
+            self.aux.wait_stream(main)
+            with torch.cuda.stream(self.aux):
+                self.graph_d.replay()                      # discriminator backward
+            self.graph_gb.replay()                         # generator backward
+        else:
+            self.graph_gb.replay()
+            self.graph_d.replay()
+        if self._sync:
+            main.synchronize()
+        d, g = self.losses
+        self.nan_flag |= torch.isnan(g['loss'].detach())
+        if not updateGen:
+            self.g_opt.arena.zero()
+        self.g_opt.finish(updateGen and self._reduce(self.g_opt, stepCounter))
+        main.wait_stream(self.aux)
+        if not updateDisc:
+            self.d_opt.arena.zero()
+        self.d_opt.finish(updateDisc and self._reduce(self.d_opt, stepCounter))      # (on the second stream instead: no faster)
         return d, g
 
     def join(self):

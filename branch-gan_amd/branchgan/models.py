@@ -354,6 +354,13 @@ def _layer_past(textualPast, i):
 def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate=None):
     """The fused block path (branchgan.fused) covers the training hot path: fp32 parameters on the GPU (bf16 compute comes
     from autocast), no dropout, engine-form past.  Everything else runs module by module."""
+    ok = _fused_covers(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate)
+    if not ok:
+        fused.module_path_forwards += 1         # graphs.py: a step with module-by-module forwards is not replayed side by side
+    return ok
+
+
+def _fused_covers(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate):
     cfg = model.config
     if not fused.ENABLED or not input_ids.is_cuda or output_hidden_states or customCasualMask is not None:
         return False

@@ -86,13 +86,14 @@ def test_graph_replays_match_eager_at_c2_shapes(amp, fused_on, monkeypatch):
     gs = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, amp, warmup=1)
     nodes, kernels, memsets, _ = map(sum, zip(*gs.census))
     assert kernels > 500
+    assert gs._side_by_side == fused_on      # the two backward graphs beside each other: only on the path whose scratch this library owns
     if not fused_on:
         assert memsets > 0                   # ATen's multi-block reductions brought memset nodes; all were replaced
     worst = 0.0
     for r in range(4):
         ids = data[1 + r]
         gs.static_ids.copy_(ids)
-        gs.graph_g.replay(); gs.graph.replay(); gs.graph_d.replay()
+        gs.replay_graphs()                   # the discriminator's backward graph beside the generator's, as a step replays them
         torch.cuda.synchronize()
         got = {k: float(v.detach()) for k, v in (("d", gs.losses[0]["loss"]), ("g", gs.losses[1]["loss"]), ("rl", gs.losses[1]["loss-RL"]))}
         g_arena, d_arena = g_opt.arena.arena.clone(), d_opt.arena.arena.clone()
