@@ -11,3 +11,5 @@ python3 $R/benchmarks/prof_summary.py $f 13 > $R/gpurun_out/r2_${T}_bench_c2_by_
 cat $R/gpurun_out/r2_${T}_bench_c2_by_class.txt
 cd $R && timeout -k 10 400 python3 bench.py > gpurun_out/r2_${T}_bench_c2_unprofiled.json 2> gpurun_out/r2_${T}_bench_c2_unprofiled.err
 tail -n 1 gpurun_out/r2_${T}_bench_c2_unprofiled.json | cut -c1-600
+t=$(ls -t $O/*/*kernel_trace.csv | head -n 1)
+python3 $R/benchmarks/step_census.py $t > $R/gpurun_out/r2_${T}_bench_c2_one_step.txt && head -n 12 $R/gpurun_out/r2_${T}_bench_c2_one_step.txt
