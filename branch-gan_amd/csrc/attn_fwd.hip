@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
 }
 
 
-// ---- key-split variant (Dh <= 128) -------------------------------------------------------------------------------------
+// ---- key-split variant (Dh <= 128; 256 in bf16) -------------------------------------------------------------------------------------
 // At Branch-GAN shapes a (batch, head) has only 32-256 query rows, so giving every wave its own 32 queries leaves most of
 // the chip idle behind one long dependent chain per wave (8 key tiles, one after the other).  Here a workgroup owns ONE
 // 32-query tile and its four waves split the KEY range: wave w takes text tiles w, w+4, ... and branch-path entries
@@ -382,12 +382,18 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
   // the query-split kernel stages each K/V tile once for four waves (measured crossover at 128 rows, MI355X, Dh 64)
   const int64_t R = (int64_t)sh.NQ * sh.K;
   static const bool all_split = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_SPLIT_ALL"); return !(e && e[0] == '0'); }();   // A/B runs
-  const bool split = sh.Dh <= 128 && (all_split || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
+  // Dh 256: the four waves' K / V tiles + the Q tile fit the 160 KB of LDS in bf16 only (152 KB; fp32 would need 280 KB)
+  static const bool split_256 = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_SPLIT_256"); return !(e && e[0] == '0'); }();
+  const bool fits = sh.Dh <= 128 || (sh.Dh == 256 && sizeof(T) == 2 && split_256);
+  const bool split = fits && (all_split || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
   if (split) {
     switch (sh.Dh) {
       case 32: launch_fwd_split<T, 32>(a, grid_split, st); break;
       case 64: launch_fwd_split<T, 64>(a, grid_split, st); break;
-      default: launch_fwd_split<T, 128>(a, grid_split, st); break;
+      case 128: launch_fwd_split<T, 128>(a, grid_split, st); break;
+      default:
+        if constexpr (sizeof(T) == 2) launch_fwd_split<T, 256>(a, grid_split, st);
+        break;
     }
     return BG_OK;
   }
