@@ -457,6 +457,14 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_batch)
     print(json.dumps(out))
+    if os.environ.get("BRANCHGAN_TUNE_GEMMS"):           # training.use_tuned_gemms: the table + what this run timed
+        import torch.cuda.tunable as tunable
+        with open(os.environ["BRANCHGAN_TUNE_GEMMS"], "w") as f:
+            for k, v in tunable.get_validators():
+                f.write(f"Validator,{k},{v}\n")
+            for r in tunable.get_results():
+                f.write(",".join(str(x) for x in r) + "\n")
+        print(f"tuned GEMM table: {len(tunable.get_results())} entries -> {os.environ['BRANCHGAN_TUNE_GEMMS']}", file=sys.stderr)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -45,3 +45,19 @@ print("all graphs as a step replays them %.3f ms" % timed(gs.replay_graphs))
 print("G adam + zero         %.3f ms" % timed(lambda: g_opt._step_and_zero()))
 print("D adam + zero         %.3f ms" % timed(lambda: d_opt._step_and_zero()))
 print("census (nodes, kernels, memsets replaced, memcpys per graph):", gs.census)
+
+# potential of the discriminator's forward beside the generator's (TIMING ONLY: the D forward reads the samples the G forward
+# writes; only its pass over the real text, 2048 of 3072 rows, could really run there)
+aux2 = torch.cuda.Stream()
+
+
+def fwd_both():
+    main = torch.cuda.current_stream()
+    aux2.wait_stream(main)
+    with torch.cuda.stream(aux2):
+        gs.graph.replay()
+    gs.graph_g.replay()
+    main.wait_stream(aux2)
+
+
+print("graph (D forward + losses) on a second stream beside graph_g: %.3f ms (one after the other: the sum above)" % timed(fwd_both))

@@ -31,13 +31,15 @@ def use_tuned_gemms(path=TUNED_GEMMS):
         if not (torch.cuda.is_available() and os.path.exists(path)):
             return False
         tunable.enable(True)
-        tunable.tuning_enable(False)
+        record = os.environ.get("BRANCHGAN_TUNE_GEMMS")       # a path: time the shapes the table lacks and write table + additions there
+        tunable.tuning_enable(bool(record))
         tunable.record_untuned_enable(False)
         keep = getattr(torch._C, "_cuda_tunableop_write_file_on_exit", None)
         if keep is not None:
-            keep(False)           # read-only use of the table
-        tunable.set_filename(path, insert_device_ordinal=False)
-        return bool(tunable.read_file(path))
+            keep(bool(record))    # otherwise read-only use of the table
+        ok = bool(tunable.read_file(path))
+        tunable.set_filename(record or path, insert_device_ordinal=False)
+        return ok
     except Exception:           # an optional speed-up: never a reason to fail
         return False
 
