@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 
-TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning", "tunableop_gfx950_gpt2_small.csv")
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuning", "tunableop_gfx950.csv")
 
 
 def use_tuned_gemms(path=TUNED_GEMMS):
