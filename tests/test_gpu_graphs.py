@@ -5,6 +5,8 @@ block path and on the module-by-module path, fp32 and bf16, over four replays.
 
 Both runs execute the same kernels on the same inputs (greedy TOP_K sampling is deterministic), so fp32 results agree to
 rounding noise: rtol 1e-5 / atol 1e-6 on the losses, rtol 1e-4 / atol 1e-6 on the parameters after 4 optimizer steps."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -182,3 +184,23 @@ def test_update_flags_and_depth_guard():
     shallow = configs.SamplingConfig(conf.rules[:2], includeAllMultiStepSamplesForDisc=True, numSampleSequences=8)
     with pytest.raises(ValueError, match="depth"):
         gs.step(data[1], 1, sampleConf=shallow)
+
+
+def test_training_with_backward_graphs_side_by_side_equals_one_after_the_other():
+    """40 optimizer steps of the bench workload c1 (graphed, bf16, Adam) with the discriminator's backward graph replayed beside
+    the generator's (the default on one rank) and with the graphs replayed in turn: the same final losses to the last bit
+    (at configs[1]: 200 steps, profiles / DESIGN §5 item 12).  Anything the two graphs shared - pool memory, a GEMM workspace,
+    scratch - would show here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    losses = {}
+    for overlap in ("1", "0"):
+        env = dict(os.environ, BRANCHGAN_OVERLAP_BWD=overlap)
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--steps", "40", "--warmup", "2",
+                              "--no-cpu-baseline", "--no-fp32", "--no-rooflines"], env=env, capture_output=True, text=True, timeout=280)
+        assert run.returncode == 0, run.stderr[-2000:]
+        losses[overlap] = json.loads(run.stdout.strip().splitlines()[-1])["config"]["final_losses"]
+    assert losses["1"] == losses["0"], losses
+    assert all(abs(v) < 1e4 for v in losses["1"].values())
