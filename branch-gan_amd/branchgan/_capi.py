@@ -72,6 +72,7 @@ SIGNATURES = {
     "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "bg_add_layernorm_pair_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz,
                                  c_vp]),

@@ -264,17 +264,23 @@ def supported_width(C_):
 # ---------------------------------------------------------------------------------------------------------------------
 # LayerNorm (+ residual add)
 # ---------------------------------------------------------------------------------------------------------------------
-def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None):
+def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None, pair=None, y_b=None):
+    """pair = (gamma_b, beta_b): a second LayerNorm of the same rows (-> y_b, returned last)."""
     rows, C_ = x2.shape
     if y is None:
         y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
+    if pair is not None and y_b is None:
+        y_b = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
     x_out = torch.empty_like(x2) if delta2 is not None else None
     with ops._timed("add_layernorm_fwd"):
-        C.check(C.lib().bg_add_layernorm_fwd(C.ptr(x2), C.ptr(delta2), C.ptr(second), C.dtype_code(delta2) if delta2 is not None else 0, rows, C_,
-                                             C.ptr(gamma), C.ptr(beta), float(eps), C.ptr(x_out), C.ptr(y), C.dtype_code(y),
-                                             C.ptr(mean), C.ptr(rstd), C.stream_ptr()), "bg_add_layernorm_fwd")
+        C.check(C.lib().bg_add_layernorm_pair_fwd(C.ptr(x2), C.ptr(delta2), C.ptr(second), C.dtype_code(delta2) if delta2 is not None else 0, rows, C_,
+                                                  C.ptr(gamma), C.ptr(beta), C.ptr(pair[0]) if pair else None, C.ptr(pair[1]) if pair else None,
+                                                  float(eps), C.ptr(x_out), C.ptr(y), C.ptr(y_b) if pair else None, C.dtype_code(y),
+                                                  C.ptr(mean), C.ptr(rstd), C.stream_ptr()), "bg_add_layernorm_pair_fwd")
+    if pair is not None:
+        return x_out, y, mean, rstd, y_b
     return x_out, y, mean, rstd
 
 
@@ -368,6 +374,74 @@ class _AddLayerNorm(torch.autograd.Function):
         shape = dy.shape
         dd = (dx_lp if dx_lp is not None else dx).view(shape)
         return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None), None, None
+
+
+class _AddLayerNormPair(torch.autograd.Function):
+    """(x [+ delta [+ delta_b]]) normalised TWICE (two LayerNorms, one eps) in one pass: the parallel-residual GPT-NeoX block, whose
+    attention and MLP branches each have a LayerNorm of the same residual stream.  -> (x + deltas [fp32], y_a, y_b).  Backward:
+    the two LayerNorm backward kernels in a row, the second adding onto the first's result (and writing the low-precision copy
+    the deltas' producers want)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, delta_b, gamma_a, beta_a, gamma_b, beta_b, eps, out_dtype, bufs):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        d2 = delta.reshape(x2.shape).contiguous() if delta is not None else None
+        db2 = delta_b.reshape(x2.shape).to(delta.dtype).contiguous() if delta_b is not None else None
+        ya, yb = bufs if bufs else (None, None)
+        x_out, y, mean, rstd, y_b = _ln_fwd(x2, d2, gamma_a.detach(), beta_a.detach(), eps, out_dtype, db2, y=ya,
+                                            pair=(gamma_b.detach(), beta_b.detach()), y_b=yb)
+        x_sum = x_out if x_out is not None else x2
+        ctx.save_for_backward(x_sum, mean, rstd)
+        ctx.params = (gamma_a, beta_a, gamma_b, beta_b)
+        ctx.delta_dtype = delta.dtype if delta is not None else None
+        ctx.n_delta = (delta is not None) + (delta_b is not None)
+        ctx.set_materialize_grads(False)
+        if x_out is None:                     # no update: the caller keeps its x (an input is not handed back as an output)
+            first = x2.new_empty(0)
+            ctx.mark_non_differentiable(first)
+        else:
+            first = x_out.view(x.shape)
+        return first, y.view(x.shape), y_b.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dx_new, dy_a, dy_b):
+        x_sum, mean, rstd = ctx.saved_tensors
+        gamma_a, beta_a, gamma_b, beta_b = ctx.params
+        none = (None,) * 10
+        if dx_new is None and dy_a is None and dy_b is None:
+            return none
+        shape = (dx_new if dx_new is not None else (dy_a if dy_a is not None else dy_b)).shape
+        dres = dx_new.reshape(x_sum.shape).contiguous().float() if dx_new is not None else None
+        lp = ctx.delta_dtype if ctx.n_delta else None
+        dg_a = db_a = dg_b = db_b = None
+        dx_lp = None
+        todo = [(dy, g, b) for dy, g, b in ((dy_a, gamma_a, beta_a), (dy_b, gamma_b, beta_b)) if dy is not None]
+        for i, (dy, g, b) in enumerate(todo):
+            last = i == len(todo) - 1
+            dres, dx_lp, dg, db, _ = _ln_bwd(dy.reshape(x_sum.shape).contiguous(), x_sum, mean, rstd, g, b, dres, lp if last else None)
+            if g is gamma_a:
+                dg_a, db_a = dg, db
+            else:
+                dg_b, db_b = dg, db
+        if not todo and lp not in (None, torch.float32):
+            dx_lp = dres.to(lp)
+        dd = (dx_lp if dx_lp is not None else dres).view(shape) if ctx.n_delta else None
+        return (dres.view(shape), dd, dd if ctx.n_delta == 2 else None, dg_a, db_a, dg_b, db_b, None, None, None)
+
+
+def add_layer_norm_pair(x, delta, ln_a, ln_b, out_dtype, delta_b=None, out_for=(None, None)):
+    """-> (x + delta + delta_b [fp32; x itself without deltas], ln_a of it, ln_b of it) in one kernel.  Falls back to two calls when
+    the two LayerNorms differ in eps."""
+    if ln_a.eps != ln_b.eps:
+        if delta is None:
+            return x, layer_norm(x, ln_a, out_dtype, out_for=out_for[0]), layer_norm(x, ln_b, out_dtype, out_for=out_for[1])
+        x1, ya = add_layer_norm(x, delta, ln_a, out_dtype, delta_b=delta_b, out_for=out_for[0])
+        return x1, ya, layer_norm(x1, ln_b, out_dtype, out_for=out_for[1])
+    rows, C_ = x.numel() // x.shape[-1], x.shape[-1]
+    bufs = (_x_slab_for(out_for[0], rows, C_, out_dtype, x.device), _x_slab_for(out_for[1], rows, C_, out_dtype, x.device))
+    x1, ya, yb = _AddLayerNormPair.apply(x, delta, delta_b, ln_a.weight, ln_a.bias, ln_b.weight, ln_b.bias, ln_a.eps, out_dtype,
+                                         bufs if (bufs[0] is not None or bufs[1] is not None) else None)
+    return (x if delta is None else x1), ya, yb
 
 
 def _x_slab_for(weight, rows, n, dtype, device):

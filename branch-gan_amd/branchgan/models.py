@@ -255,6 +255,15 @@ class GPTNeoXLayer(nn.Module):
         added in the LayerNorm kernel); returns (x + delta, this block's update, present).
         Parallel residual: both LayerNorms read x + delta, the update is attention + MLP."""
         qkv_w, up_w, down_w = self.attention.query_key_value.weight, self.mlp.dense_h_to_4h.weight, self.mlp.dense_4h_to_h.weight
+        if self.use_parallel_residual:
+            # both LayerNorms read the same x + delta: one kernel, one set of row statistics
+            pair = (delta if isinstance(delta, tuple) else (delta, None))
+            x1, h1, h2 = fused.add_layer_norm_pair(x, pair[0], self.input_layernorm, self.post_attention_layernorm, dtype, delta_b=pair[1],
+                                                   out_for=(qkv_w, up_w))
+            a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
+            g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
+            m = fused.linear(g, down_w, self.mlp.dense_4h_to_h.bias, "oi", dtype)
+            return x1, (a, m), present
         if delta is None:
             x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype, out_for=qkv_w)
         elif isinstance(delta, tuple):
@@ -262,11 +271,6 @@ class GPTNeoXLayer(nn.Module):
         else:
             x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype, out_for=qkv_w)
         a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
-        if self.use_parallel_residual:
-            h2 = fused.layer_norm(x1, self.post_attention_layernorm, dtype, out_for=up_w)
-            g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
-            m = fused.linear(g, down_w, self.mlp.dense_4h_to_h.bias, "oi", dtype)
-            return x1, (a, m), present
         x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias, out_for=up_w,
                                       delta_from=self.attention.dense.weight)
         g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)

@@ -52,6 +52,9 @@ struct LnFwdArgs {
   int64_t rows;
   int C;
   float eps;
+  const float* gamma_b;   // optional second LayerNorm of the same row (parallel-residual blocks normalise x + delta twice)
+  const float* beta_b;
+  void* y_b;
 };
 
 // TD: dtype of delta (ignored when delta == nullptr), TY: dtype of y
@@ -118,6 +121,13 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       store4<TY>(y + c, o);
+      if (a.y_b) {
+        load4<float>(a.gamma_b + c, g);
+        load4<float>(a.beta_b + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        store4<TY>((TY*)a.y_b + r * C + c, o);
+      }
     }
   }
 }
@@ -442,7 +452,16 @@ static bool al16(const void* p) { return p && (((uintptr_t)p) & 15) == 0; }
 extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C, const float* gamma,
                                     const float* beta, float eps, float* x_out, void* y, int y_dtype, float* mean, float* rstd,
                                     void* stream) {
+  return bg_add_layernorm_pair_fwd(x, delta, delta2, delta_dtype, rows, C, gamma, beta, nullptr, nullptr, eps, x_out, y, nullptr, y_dtype, mean, rstd,
+                                   stream);
+}
+
+extern "C" int bg_add_layernorm_pair_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
+                                         const float* gamma, const float* beta, const float* gamma_b, const float* beta_b, float eps,
+                                         float* x_out, void* y, void* y_b, int y_dtype, float* mean, float* rstd, void* stream) {
   BG_REQUIRE(x && gamma && beta && y && mean && rstd, "bg_add_layernorm_fwd: null argument");
+  BG_REQUIRE((y_b == nullptr) == (gamma_b == nullptr) && (y_b == nullptr) == (beta_b == nullptr) && (!y_b || (al16(gamma_b) && al16(beta_b) && (((uintptr_t)y_b) & 7) == 0)),
+             "bg_add_layernorm_pair_fwd: gamma_b, beta_b and y_b are given together (16-byte aligned; 8 for a bf16 y_b), or all NULL");
   BG_REQUIRE(rows > 0 && rows < (1ll << 31), "bg_add_layernorm_fwd: rows=%lld", (long long)rows);
   BG_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * LN_MAX_NV, "bg_add_layernorm_fwd: C=%d must be a multiple of 4, at most %d", C, 256 * LN_MAX_NV);
   BG_REQUIRE(dtype_ok(y_dtype) && (!delta || dtype_ok(delta_dtype)), "bg_add_layernorm_fwd: dtype");
@@ -450,7 +469,7 @@ extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, const voi
   BG_REQUIRE(!delta2 || (delta && (((uintptr_t)delta2) & 7) == 0), "bg_add_layernorm_fwd: delta2 without delta, or misaligned");
   BG_REQUIRE(al16(x) && al16(gamma) && al16(beta) && (!delta || (((uintptr_t)delta) & 7) == 0) && (!delta || al16(x_out)) && (((uintptr_t)y) & 7) == 0,
              "bg_add_layernorm_fwd: pointers must be 16-byte aligned (8 for bf16)");
-  LnFwdArgs a{x, delta, delta2, gamma, beta, x_out, y, mean, rstd, rows, C, eps};
+  LnFwdArgs a{x, delta, delta2, gamma, beta, x_out, y, mean, rstd, rows, C, eps, gamma_b, beta_b, y_b};
   hipStream_t st = (hipStream_t)stream;
   const bool dbf = delta && delta_dtype == BG_BF16;
   if (y_dtype == BG_BF16) {

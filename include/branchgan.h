@@ -263,6 +263,13 @@ int bg_bias_act_bwd_groups(int64_t rows);
 int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
                          const float* gamma, const float* beta, float eps,
                          float* x_out, void* y, int y_dtype, float* mean, float* rstd, void* stream);
+/* The same with a SECOND LayerNorm of the same row: y_b = LayerNorm(x + delta + delta2; gamma_b, beta_b) beside y (one pass, one
+ * mean / rstd).  For the parallel-residual GPT-NeoX block, whose attention and MLP branches each normalise the same residual
+ * stream (NeoXNonResidualBase.py:117-126: input_layernorm and post_attention_layernorm of hidden_states).  gamma_b, beta_b, y_b
+ * are given together or all NULL (= bg_add_layernorm_fwd). */
+int bg_add_layernorm_pair_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
+                              const float* gamma, const float* beta, const float* gamma_b, const float* beta_b, float eps,
+                              float* x_out, void* y, void* y_b, int y_dtype, float* mean, float* rstd, void* stream);
 size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* dres, int64_t rows, int C,

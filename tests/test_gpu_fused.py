@@ -441,3 +441,44 @@ def test_stacked_activations_written_in_place(monkeypatch):
     relaid, s6 = grads(True)                       # the late backward pass laid out stacks of its own: back to the two-pass layout
     last, s7 = grads(True)
     assert torch.equal(relaid, ref) and s7 == s2 and torch.equal(last, ref)
+
+
+@pytest.mark.parametrize("lowp", [False, True])
+@pytest.mark.parametrize("n_delta", [0, 1, 2])
+def test_add_layernorm_pair_equals_two_layernorms(lowp, n_delta):
+    """fused.add_layer_norm_pair (one kernel, two LayerNorms of x + deltas: the parallel-residual NeoX block) against
+    add_layer_norm / layer_norm one after the other: outputs bit-identical, every gradient equal to summation order."""
+    from branchgan import fused
+    torch.manual_seed(4)
+    rows, C_ = 300, 1024
+    dt = torch.bfloat16 if lowp else torch.float32
+    ln_a, ln_b = torch.nn.LayerNorm(C_).cuda(), torch.nn.LayerNorm(C_).cuda()
+    for ln in (ln_a, ln_b):
+        ln.weight.data.normal_(1.0, 0.2)
+        ln.bias.data.normal_(0.0, 0.2)
+    x0 = torch.randn(2, rows // 2, C_, device="cuda")
+    d0 = [torch.randn(2, rows // 2, C_, device="cuda").to(dt) for _ in range(n_delta)]
+    wa, wb, wx = (torch.randn(2, rows // 2, C_, device="cuda") for _ in range(3))
+
+    def run(pair):
+        for ln in (ln_a, ln_b):
+            ln.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        ds = [d.clone().requires_grad_(True) for d in d0]
+        if pair:
+            x1, ya, yb = fused.add_layer_norm_pair(x, ds[0] if ds else None, ln_a, ln_b, dt, delta_b=ds[1] if n_delta == 2 else None)
+        elif not ds:
+            x1, ya, yb = x, fused.layer_norm(x, ln_a, dt), fused.layer_norm(x, ln_b, dt)
+        else:
+            x1, ya = fused.add_layer_norm(x, ds[0], ln_a, dt, delta_b=ds[1] if n_delta == 2 else None)
+            yb = fused.layer_norm(x1, ln_b, dt)
+        ((ya.float() * wa).sum() + (yb.float() * wb).sum() * 0.5 + (x1 * wx).sum() * 0.25).backward()
+        grads = [x.grad] + [d.grad for d in ds] + [ln_a.weight.grad, ln_a.bias.grad, ln_b.weight.grad, ln_b.bias.grad]
+        return (x1.detach(), ya.detach(), yb.detach()), [g.detach().clone().float() for g in grads]
+
+    (x1_r, ya_r, yb_r), g_ref = run(False)
+    (x1_p, ya_p, yb_p), g_pair = run(True)
+    assert torch.equal(x1_p, x1_r) and torch.equal(ya_p, ya_r) and torch.equal(yb_p, yb_r)
+    for a, b in zip(g_pair, g_ref):
+        tol = 2e-2 if lowp else 1e-4
+        assert float((a - b).abs().max()) <= tol * (1.0 + float(b.abs().max())), float((a - b).abs().max())
