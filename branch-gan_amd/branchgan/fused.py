@@ -383,7 +383,8 @@ class _AddLayerNormPair(torch.autograd.Function):
     the deltas' producers want)."""
 
     @staticmethod
-    def forward(ctx, x, delta, delta_b, gamma_a, beta_a, gamma_b, beta_b, eps, out_dtype, bufs):
+    def forward(ctx, x, delta, delta_b, gamma_a, beta_a, gamma_b, beta_b, eps, out_dtype, bufs, delta_from=None):
+        ctx.delta_from = delta_from
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         d2 = delta.reshape(x2.shape).contiguous() if delta is not None else None
         db2 = delta_b.reshape(x2.shape).to(delta.dtype).contiguous() if delta_b is not None else None
@@ -407,7 +408,7 @@ class _AddLayerNormPair(torch.autograd.Function):
     def backward(ctx, dx_new, dy_a, dy_b):
         x_sum, mean, rstd = ctx.saved_tensors
         gamma_a, beta_a, gamma_b, beta_b = ctx.params
-        none = (None,) * 10
+        none = (None,) * 11
         if dx_new is None and dy_a is None and dy_b is None:
             return none
         shape = (dx_new if dx_new is not None else (dy_a if dy_a is not None else dy_b)).shape
@@ -418,7 +419,8 @@ class _AddLayerNormPair(torch.autograd.Function):
         todo = [(dy, g, b) for dy, g, b in ((dy_a, gamma_a, beta_a), (dy_b, gamma_b, beta_b)) if dy is not None]
         for i, (dy, g, b) in enumerate(todo):
             last = i == len(todo) - 1
-            dres, dx_lp, dg, db, _ = _ln_bwd(dy.reshape(x_sum.shape).contiguous(), x_sum, mean, rstd, g, b, dres, lp if last else None)
+            dres, dx_lp, dg, db, _ = _ln_bwd(dy.reshape(x_sum.shape).contiguous(), x_sum, mean, rstd, g, b, dres, lp if last else None,
+                                             None, ctx.delta_from if last else None)
             if g is gamma_a:
                 dg_a, db_a = dg, db
             else:
@@ -426,10 +428,19 @@ class _AddLayerNormPair(torch.autograd.Function):
         if not todo and lp not in (None, torch.float32):
             dx_lp = dres.to(lp)
         dd = (dx_lp if dx_lp is not None else dres).view(shape) if ctx.n_delta else None
-        return (dres.view(shape), dd, dd if ctx.n_delta == 2 else None, dg_a, db_a, dg_b, db_b, None, None, None)
+        return (dres.view(shape), dd, dd if ctx.n_delta == 2 else None, dg_a, db_a, dg_b, db_b, None, None, None, None)
 
 
-def add_layer_norm_pair(x, delta, ln_a, ln_b, out_dtype, delta_b=None, out_for=(None, None)):
+def dy_buffer_of(weight, device):
+    """-> a callable (rows, features, dtype) -> buffer-or-None for the producer of the output gradient of `weight`'s latest
+    projection (its slab of the dy stack), or None when there is nothing to aim at."""
+    target = _pass_of(weight, device)
+    if target is None:
+        return None
+    return lambda rows, n, dtype: _deferred_dw_for(device).dy_slab(target[0], target[1], rows, n, dtype)
+
+
+def add_layer_norm_pair(x, delta, ln_a, ln_b, out_dtype, delta_b=None, out_for=(None, None), delta_from=None):
     """-> (x + delta + delta_b [fp32; x itself without deltas], ln_a of it, ln_b of it) in one kernel.  Falls back to two calls when
     the two LayerNorms differ in eps."""
     if ln_a.eps != ln_b.eps:
@@ -440,7 +451,8 @@ def add_layer_norm_pair(x, delta, ln_a, ln_b, out_dtype, delta_b=None, out_for=(
     rows, C_ = x.numel() // x.shape[-1], x.shape[-1]
     bufs = (_x_slab_for(out_for[0], rows, C_, out_dtype, x.device), _x_slab_for(out_for[1], rows, C_, out_dtype, x.device))
     x1, ya, yb = _AddLayerNormPair.apply(x, delta, delta_b, ln_a.weight, ln_a.bias, ln_b.weight, ln_b.bias, ln_a.eps, out_dtype,
-                                         bufs if (bufs[0] is not None or bufs[1] is not None) else None)
+                                         bufs if (bufs[0] is not None or bufs[1] is not None) else None,
+                                         _pass_of(delta_from, x.device) if delta is not None else None)
     return (x if delta is None else x1), ya, yb
 
 

@@ -203,13 +203,16 @@ def _neox_fused_attention(at, h1, pos, dtype, lp):
     B, T, _ = h1.shape
     qkv = fused.linear(h1, at.query_key_value.weight, at.query_key_value.bias, "oi", dtype)
     cos, sin = rope_tables(at.rotary_ndims, at.config.max_position_embeddings, at.config.rotary_emb_base, qkv.device)
-    query, key, value = ops.neox_qkv_rope(qkv, cos, sin, pos, at.num_attention_heads, at.head_size, at.rotary_ndims)
+    # the gradient of qkv goes straight into the stacked operands of the batched weight-gradient GEMMs
+    # (fused._DeferredWeightGrads), like the LayerNorm / GELU outputs of the block
+    query, key, value = ops.neox_qkv_rope(qkv, cos, sin, pos, at.num_attention_heads, at.head_size, at.rotary_ndims,
+                                          grad_buffer=fused.dy_buffer_of(at.query_key_value.weight, qkv.device))
     scale = 1.0 / at.norm_factor
     if lp is not None:
         out = branch_attention_core(query, key, value, lp, scale)
     else:
         out, _ = ops.causal_attention(query, key, value, scale=scale)
-    out = out.permute(0, 2, 1, 3).reshape(B, T, at.hidden_size)
+    out = out.permute(0, 2, 1, 3).reshape(B, T, at.hidden_size)        # (into the x stack by copy_: autograd's CopySlices costs more than the stack copy)
     return fused.linear(out, at.dense.weight, at.dense.bias, "oi", dtype), (key, value)
 
 
@@ -249,8 +252,9 @@ class GPTNeoXLayer(nn.Module):
             hidden_states = drop(self.mlp(self.post_attention_layernorm(attn_output))) + attn_output
         return hidden_states, present
 
-    def fused_forward(self, x, delta, dtype, pos, lp):
-        """Same block on the fused path (see NonResidualGPT2Block.fused_forward).  `x` is the fp32 residual stream BEFORE the
+    def fused_forward(self, x, delta, dtype, pos, lp, delta_from=None):
+        """Same block on the fused path (see NonResidualGPT2Block.fused_forward; delta_from: the weight of the projection whose
+        output gradient this block's LayerNorm backward produces - the previous block's attention.dense).  `x` is the fp32 residual stream BEFORE the
         previous block's update `delta` (None for the first block; a pair (attention, MLP) after a parallel-residual block,
         added in the LayerNorm kernel); returns (x + delta, this block's update, present).
         Parallel residual: both LayerNorms read x + delta, the update is attention + MLP."""
@@ -259,7 +263,7 @@ class GPTNeoXLayer(nn.Module):
             # both LayerNorms read the same x + delta: one kernel, one set of row statistics
             pair = (delta if isinstance(delta, tuple) else (delta, None))
             x1, h1, h2 = fused.add_layer_norm_pair(x, pair[0], self.input_layernorm, self.post_attention_layernorm, dtype, delta_b=pair[1],
-                                                   out_for=(qkv_w, up_w))
+                                                   out_for=(qkv_w, up_w), delta_from=delta_from)
             a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
             g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
             m = fused.linear(g, down_w, self.mlp.dense_4h_to_h.bias, "oi", dtype)
@@ -407,11 +411,14 @@ class GPTNeoXForCausalLM(_LMBase):
             pos = pos.contiguous()          # once, not per layer (an expanded view otherwise)
             with torch.autocast("cuda", enabled=False):
                 x, delta, presents = fused.embedding(input_ids, None, self.gpt_neox.embed_in.weight), None, []
+                delta_from = None
                 for i, layer in enumerate(self.gpt_neox.layers):
-                    x, delta, present = layer.fused_forward(x, delta, dtype, pos, _layer_past(textualPast, i) if branch else None)
+                    x, delta, present = layer.fused_forward(x, delta, dtype, pos, _layer_past(textualPast, i) if branch else None,
+                                                            delta_from)
+                    delta_from = layer.attention.dense.weight if layer.use_parallel_residual else None
                     presents.append(present)
                 if isinstance(delta, tuple):
-                    _, y = fused.add_layer_norm(x, delta[0], self.gpt_neox.final_layer_norm, dtype, delta_b=delta[1])
+                    _, y = fused.add_layer_norm(x, delta[0], self.gpt_neox.final_layer_norm, dtype, delta_b=delta[1], delta_from=delta_from)
                 else:
                     _, y = fused.add_layer_norm(x, delta, self.gpt_neox.final_layer_norm, dtype)
                 head = self.embed_out if returnLmLogits else self.valueHead

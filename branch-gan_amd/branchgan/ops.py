@@ -452,7 +452,8 @@ def causal_attention(q, k, v, scale=None):
 # ---------------------------------------------------------------------------------------------------
 class _NeoxQkvRope(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cos_tab, sin_tab, position_ids, H, Dh, rot):
+    def forward(ctx, qkv, cos_tab, sin_tab, position_ids, H, Dh, rot, grad_buffer=None):
+        ctx.grad_buffer = grad_buffer
         C.require_cuda(qkv, cos_tab, sin_tab, position_ids)
         qkv = qkv.contiguous()
         B, T = qkv.shape[:2]
@@ -473,16 +474,18 @@ class _NeoxQkvRope(torch.autograd.Function):
         dq = dq.contiguous() if dq is not None else zeros()
         dk = dk.contiguous() if dk is not None else zeros()
         dv = dv.contiguous() if dv is not None else zeros()
-        dqkv = torch.empty((B, T, H * 3 * Dh), dtype=dtype, device=pos.device)
+        dqkv = ctx.grad_buffer(B * T, H * 3 * Dh, dtype) if ctx.grad_buffer is not None else None
+        dqkv = dqkv.view(B, T, H * 3 * Dh) if dqkv is not None else torch.empty((B, T, H * 3 * Dh), dtype=dtype, device=pos.device)
         C.check(C.lib().bg_neox_qkv_rope_bwd(C.ptr(dq), C.ptr(dk), C.ptr(dv), C.dtype_code(dq), B, T, H, Dh, rot, C.ptr(cos_tab),
                                              C.ptr(sin_tab), cos_tab.shape[0], C.ptr(pos), C.ptr(dqkv), C.stream_ptr()),
                 "bg_neox_qkv_rope_bwd")
-        return dqkv, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None
 
 
-def neox_qkv_rope(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims):
-    """qkv (B,T,3*hidden) in the NeoX per-head interleaved order -> q, k (rotated), v, each (B,H,T,Dh)."""
-    return _NeoxQkvRope.apply(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims)
+def neox_qkv_rope(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims, grad_buffer=None):
+    """qkv (B,T,3*hidden) in the NeoX per-head interleaved order -> q, k (rotated), v, each (B,H,T,Dh).
+    grad_buffer(rows, features, dtype) -> a contiguous buffer for the gradient of qkv, or None (fused.py: the dy stack of the projection)."""
+    return _NeoxQkvRope.apply(qkv, cos_tab, sin_tab, position_ids, n_head, head_dim, rot_dims, grad_buffer)
 
 
 # ---------------------------------------------------------------------------------------------------
