@@ -135,6 +135,8 @@ class GraphedTrainStep:
         self._pending_d = None
         # one rank: the discriminator's backward graph is replayed on a second stream BESIDE the generator's (see _step)
         self._overlap = (not self._defer_d) if os.environ.get("BRANCHGAN_OVERLAP_BWD") is None else os.environ["BRANCHGAN_OVERLAP_BWD"] == "1"
+        if not hasattr(torch._C, "_cuda_clearCublasWorkspaces"):      # no way to give each graph its own GEMM workspace: one after the other
+            self._overlap = False
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
         # exponential noise of the race techniques: persistent tensors, one per sampling call of a step, refreshed before a replay
         self._noise, self._noise_cursor, self._user_noise = [], 0, model.noise_fn
