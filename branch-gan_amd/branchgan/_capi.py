@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbranchgan_hip.so")
 BG_F32, BG_BF16 = 0, 1
 MAX_TOPN, MAX_BLOCKED, MAX_SLOTS, MAX_GATHER = 64, 8, 64, 80
 MAX_RANKS = 8
+RL_DIAG_COUNT = 20
 
 c_i64, c_i32, c_f32, c_vp, c_sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 c_f64 = ctypes.c_double
@@ -88,7 +89,7 @@ SIGNATURES = {
     "bg_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_i64, c_f64, c_i32, c_vp]),
     "bg_disc_loss_fwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp, c_vp]),
     "bg_disc_loss_bwd": (c_i32, [ctypes.POINTER(DiscLossShape)] + [c_vp] * 9 + [c_vp] + [c_vp] * 5 + [c_vp]),
-    "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp]),
+    "bg_rl_loss_fwd": (c_i32, [ctypes.POINTER(RlLossShape)] + [c_vp] * 7 + [c_vp, c_vp, c_vp]),
     "bg_dual_head_advantages": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_f32] * 3 + [c_i32] * 2 + [c_f32] * 2 + [c_vp] * 6 + [c_vp]),
     "bg_reinforce_terms_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),
     "bg_reinforce_terms_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),

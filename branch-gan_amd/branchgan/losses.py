@@ -54,8 +54,9 @@ def calcDiscriminatorLoss(gannSetup, inputScores, alterationScores, numNegativeU
 
 
 def reinforceLosses(labelLogProbs, alterationLogProbs, discInputScores, discAlterationScores, txtInputPreds, txtAlterationsPreds,
-                    reinforcementLearningConfig, depthMask=None, probs_input=False):
-    """_reinforceLoss (GeneratorLosses.py:84-131) -> dict input / alterations / combined / unweightedCombined."""
+                    reinforcementLearningConfig, depthMask=None, probs_input=False, debugStats=None):
+    """_reinforceLoss (GeneratorLosses.py:84-131) -> dict input / alterations / combined / unweightedCombined.  debugStats: a
+    dict that receives the twenty entries of _calculateDebuggingStats (:34-81), 0-dim views of one device tensor."""
     cfg = reinforcementLearningConfig
     if cfg.teacherForcing:
         discInputScores = torch.ones_like(discInputScores)
@@ -65,7 +66,11 @@ def reinforceLosses(labelLogProbs, alterationLogProbs, discInputScores, discAlte
                         txtInputPreds.squeeze(-1), txtAlterationsPreds.squeeze(-1),
                         None if depthMask is None else depthMask[:, :K], w.A, w.B, w.C,
                         cfg.inputIncorrectValueHeadsPolicy == IncorrectValueHeadsPolicy.IGNORE_SAMPLE,
-                        cfg.alterationIncorrectValueHeadsPolicy == IncorrectValueHeadsPolicy.IGNORE_SAMPLE, probs_input)
+                        cfg.alterationIncorrectValueHeadsPolicy == IncorrectValueHeadsPolicy.IGNORE_SAMPLE, probs_input,
+                        diagnostics=debugStats is not None)
+    if debugStats is not None:
+        out, diag = out
+        debugStats.update(zip(ops.RL_DIAG_KEYS, diag.unbind(0)))
     inputLoss, alterationLoss = out[0], out[1]
     N = discAlterationScores.shape[1]
     return {'input': inputLoss, 'alterations': alterationLoss, 'combined': (inputLoss + alterationLoss) / 2,
@@ -134,9 +139,11 @@ def calcGeneratorLoss(gannSetup, inputIDs, generatorLogits, generatorProbs, disc
     if altLogProbs is None:                      # reference-style dict: probabilities, 1e-5 padded to S columns
         K = _real_columns(data, forwardPassData['AlterationProbs'].shape[-1])
         altLogProbs, labelLogProbs, probs_input = forwardPassData['AlterationProbs'][:, :, :K], labelLogProbs.exp(), True
+    rlLossInfo = {}
     rl = reinforceLosses(labelLogProbs, altLogProbs, discInputScores.detach(), discAlterationScores.detach(),
                          data['txtInputPreds'].detach(), data['txtAlterationsPreds'].detach(), reinforcementLearningConfig,
-                         depthMask=depthMask, probs_input=probs_input)
+                         depthMask=depthMask, probs_input=probs_input, debugStats=rlLossInfo)
+    genLosses.update(rlLossInfo)                 # the reference's key order: MLE, the debugging stats, loss-RL-*, loss-RL, loss
     for k, v in rl.items():
         genLosses['loss-RL-{}'.format(k)] = v
     mode = reinforcementLearningConfig.labelMode

@@ -554,7 +554,7 @@ def disc_losses(input_scores, alt_scores, txt_in, txt_alt, alt_alt, depth_mask, 
 class _RlLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask, wA, wB, wC, ignore_in, ignore_alt,
-                probs_input):
+                probs_input, diagnostics):
         C.require_cuda(label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask)
         B, S = input_scores.shape
         _, N, K = alt_scores.shape
@@ -563,31 +563,42 @@ class _RlLosses(torch.autograd.Function):
         args = [_f32c(t) for t in (input_scores, alt_scores, in_head, alt_head, label_lp, alt_lp)]
         mask = _f32c(depth_mask) if depth_mask is not None else None
         out = torch.empty(2, dtype=torch.float32, device=input_scores.device)
-        C.check(C.lib().bg_rl_loss_fwd(ctypes.byref(sh), *[C.ptr(t) for t in args], C.ptr(mask), C.ptr(out), C.stream_ptr()),
-                "bg_rl_loss_fwd")
+        diag = torch.empty(C.RL_DIAG_COUNT if diagnostics else 0, dtype=torch.float32, device=input_scores.device)
+        C.check(C.lib().bg_rl_loss_fwd(ctypes.byref(sh), *[C.ptr(t) for t in args], C.ptr(mask), C.ptr(out),
+                                       C.ptr(diag) if diagnostics else None, C.stream_ptr()), "bg_rl_loss_fwd")
         ctx.save_for_backward(*args, *([mask] if mask is not None else []))
         ctx.sh = sh
         ctx.shapes = (label_lp.shape, alt_lp.shape)
-        return out
+        ctx.mark_non_differentiable(diag)
+        return out, diag
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, _g_diag):
         saved = ctx.saved_tensors
         args, mask = list(saved[:6]), (saved[6] if len(saved) > 6 else None)
         d_label, d_alt = torch.empty_like(args[4]), torch.empty_like(args[5])
         g = g_out.contiguous().float()
         C.check(C.lib().bg_rl_loss_bwd(ctypes.byref(ctx.sh), *[C.ptr(t) for t in args], C.ptr(mask), C.ptr(g), C.ptr(d_label),
                                        C.ptr(d_alt), C.stream_ptr()), "bg_rl_loss_bwd")
-        return (d_label.view(ctx.shapes[0]), d_alt.view(ctx.shapes[1])) + (None,) * 11
+        return (d_label.view(ctx.shapes[0]), d_alt.view(ctx.shapes[1])) + (None,) * 12
+
+
+RL_DIAG_KEYS = ('Rl-Loss-A-Input', 'Rl-Loss-B-Input', 'RL-Loss-C-Input', 'Rl-Loss-A-Alt', 'Rl-Loss-B-Alt', 'RL-Loss-C-Alt',
+                'Rl-Advantage-A-Input', 'Rl-Advantage-B-Input', 'RL-Advantage-C-Input', 'Rl-Advantage-A-Alt', 'Rl-Advantage-B-Alt',
+                'RL-Advantage-C-Alt', 'RL-ZoneA-Input-Factor', 'RL-ZoneB-Input-Factor', 'RL-ZoneC-Input-Factor',
+                'RL-ZoneA-Alt-Factor', 'RL-ZoneB-Alt-Factor', 'RL-ZoneC-Alt-Factor', 'RL-CorrectValueHeads-Factor',
+                'RL-CorrectInput-Factor')   # the order of GeneratorLosses.py:66-81 = the order of bg_rl_loss_fwd's out_diag
 
 
 def rl_losses(label_lp, alt_lp, input_scores, alt_scores, in_head, alt_head, depth_mask, wA=1.0, wB=1.0, wC=1.0,
-              ignore_input=True, ignore_alt=True, probs_input=False):
+              ignore_input=True, ignore_alt=True, probs_input=False, diagnostics=False):
     """Fused AdvantageCalculations.py:5-46 + ReinforceLoss.py:21-52 + GeneratorLosses.py:96-121.
     label_lp (B,S-1), alt_lp (B,N,K): log-probs (or probs with probs_input=True) of the true / sampled tokens; the
-    discriminator tensors carry no gradient.  -> fp32 [loss-RL-input, loss-RL-alterations]."""
-    return _RlLosses.apply(label_lp, alt_lp, input_scores.detach(), alt_scores.detach(), in_head.detach(), alt_head.detach(),
-                           depth_mask, wA, wB, wC, ignore_input, ignore_alt, probs_input)
+    discriminator tensors carry no gradient.  -> fp32 [loss-RL-input, loss-RL-alterations]; with diagnostics=True a pair
+    (that, fp32 [20] = _calculateDebuggingStats of GeneratorLosses.py:34-81 in RL_DIAG_KEYS order, no gradient)."""
+    out, diag = _RlLosses.apply(label_lp, alt_lp, input_scores.detach(), alt_scores.detach(), in_head.detach(), alt_head.detach(),
+                                depth_mask, wA, wB, wC, ignore_input, ignore_alt, probs_input, diagnostics)
+    return (out, diag) if diagnostics else out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -129,6 +129,7 @@ struct RlArgs {
   float* out;
   const float* g;
   float *d_label, *d_alt;
+  float* diag;  // optional fp32 [BG_RL_DIAG_COUNT]: _calculateDebuggingStats (GeneratorLosses.py:34-81), forward only
 };
 
 struct Adv { float adv; bool zone_c; };
@@ -200,6 +201,82 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_loss_kernel(RlArgs a) {
   } else {
     block_sum<3>(acc, red);
     if (tid == 0) { a.out[0] = acc[0] * inv_in; a.out[1] = acc[1] * inv_alt; }
+  }
+}
+
+// _calculateDebuggingStats (GeneratorLosses.py:34-81): the twenty diagnostics the reference's training loop logs beside the
+// generator loss, in the reference's dict order.  They are sums over the SAME per-element quantities rl_loss_kernel forms,
+// but over the reference's full (B, 1+N, S) extent: the input row keeps its last column (shifted score 0) for the advantage
+// means and zone factors and drops it ([:, :, :-1]) for the loss means; the alteration rows keep the S - K padded columns
+// (score 0, probability 1e-5) and are NOT weighted by the depth mask, except in the three zone factors.
+// A zone whose mask is empty reports 0 (the reference's `if x.sum() > 0 else 0`).
+constexpr int RL_DIAG_ACC = 26;
+
+__global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
+  __shared__ float red[RL_DIAG_ACC * 16];
+  const bg_rl_loss_shape& s = a.sh;
+  const int tid = threadIdx.x;
+  // [z]: input loss sum, input count over S-1, input advantage sum, input count over S  (z = A, B, C)
+  // [12 + z]: alteration loss sum, count, advantage sum, count under the depth mask;  [24] heads correct, [25] input correct
+  float acc[RL_DIAG_ACC];
+#pragma unroll
+  for (int i = 0; i < RL_DIAG_ACC; ++i) acc[i] = 0.f;
+  for (int i = tid; i < s.B * s.S; i += LOSS_THREADS) {
+    const int b = i / s.S, t = i % s.S;
+    const float in_h = a.in_head[i], alt_h = a.alt_head[i];
+    const float score = t + 1 < s.S ? a.in[i + 1] : 0.f;
+    const Adv ad = advantage(s, score, in_h, alt_h, s.ignore_input != 0);
+    const bool za = score >= in_h, above = score >= alt_h;
+    const bool zone[3] = {za, za != above, !above};
+    float loss = 0.f, dv;
+    if (t < s.S - 1) rl_term(s.probs_input != 0, a.label_lp[b * (s.S - 1) + t], ad, loss, dv);
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+      if (zone[z]) {
+        if (t < s.S - 1) { acc[4 * z] += loss; acc[4 * z + 1] += 1.f; }
+        acc[4 * z + 2] += ad.adv;
+        acc[4 * z + 3] += 1.f;
+      }
+    acc[24] += alt_h >= in_h ? 0.f : 1.f;
+    acc[25] += a.in[i] >= alt_h ? 1.f : 0.f;
+  }
+  for (int i = tid; i < s.B * s.N * s.S; i += LOSS_THREADS) {
+    const int j = i % s.S, n = (i / s.S) % s.N, b = i / (s.S * s.N);
+    const bool real = j < s.K;
+    const int64_t e = ((int64_t)b * s.N + n) * s.K + j;
+    const float score = real ? a.alt[e] : 0.f;
+    const float in_h = a.in_head[b * s.S + j], alt_h = a.alt_head[b * s.S + j];
+    const Adv ad = advantage(s, score, in_h, alt_h, s.ignore_alt != 0);
+    const bool za = score >= in_h, above = score >= alt_h;
+    const bool zone[3] = {za, za != above, !above};
+    float loss, dv;
+    if (real) rl_term(s.probs_input != 0, a.alt_lp[e], ad, loss, dv);
+    else rl_term(true, 1e-5f, ad, loss, dv);
+    const float m = (s.use_depth_mask && real) ? a.mask[n * s.K + j] : 0.f;
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+      if (zone[z]) { acc[12 + 4 * z] += loss; acc[12 + 4 * z + 1] += 1.f; acc[12 + 4 * z + 2] += ad.adv; acc[12 + 4 * z + 3] += m; }
+  }
+  float mask_sum = 0.f;
+  if (s.use_depth_mask)
+    for (int i = tid; i < s.N * s.K; i += LOSS_THREADS) mask_sum += a.mask[i];
+  block_sum<RL_DIAG_ACC>(acc, red);
+  float one[1] = {mask_sum};
+  block_sum<1>(one, red);
+  if (tid == 0) {
+    const float n_in = (float)s.B * s.S, n_alt = (float)s.B * s.N * s.S;
+    auto ratio = [](float num, float den) { return den > 0.f ? num / den : 0.f; };
+    float* d = a.diag;
+    for (int z = 0; z < 3; ++z) {
+      d[z] = ratio(acc[4 * z], acc[4 * z + 1]);                 // Rl-Loss-{A,B,C}-Input
+      d[3 + z] = ratio(acc[12 + 4 * z], acc[12 + 4 * z + 1]);   // Rl-Loss-{A,B,C}-Alt
+      d[6 + z] = ratio(acc[4 * z + 2], acc[4 * z + 3]);         // Rl-Advantage-{A,B,C}-Input
+      d[9 + z] = ratio(acc[12 + 4 * z + 2], acc[12 + 4 * z + 1]);  // Rl-Advantage-{A,B,C}-Alt
+      d[12 + z] = acc[4 * z + 3] / n_in;                        // RL-Zone{A,B,C}-Input-Factor
+      d[15 + z] = s.use_depth_mask ? ratio(acc[12 + 4 * z + 3], one[0] * (float)s.B) : acc[12 + 4 * z + 1] / n_alt;
+    }
+    d[18] = acc[24] / n_in;                                     // RL-CorrectValueHeads-Factor
+    d[19] = acc[25] / n_in;                                     // RL-CorrectInput-Factor
   }
 }
 
@@ -321,16 +398,20 @@ extern "C" int bg_disc_loss_bwd(const bg_disc_loss_shape* shape, const float* in
 
 extern "C" int bg_rl_loss_fwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
                               const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
-                              const float* depth_mask, float* out_losses, void* stream) {
+                              const float* depth_mask, float* out_losses, float* out_diag, void* stream) {
   if (int e = check_rl(shape, "bg_rl_loss_fwd")) return e;
   BG_REQUIRE(input_scores && alt_scores && in_head && alt_head && label_logp && alt_logp && out_losses && (depth_mask || !shape->use_depth_mask),
              "bg_rl_loss_fwd: null pointer");
   RlArgs a;
   memset(&a, 0, sizeof(a));
   a.sh = *shape; a.in = input_scores; a.alt = alt_scores; a.in_head = in_head; a.alt_head = alt_head; a.label_lp = label_logp;
-  a.alt_lp = alt_logp; a.mask = depth_mask; a.out = out_losses;
+  a.alt_lp = alt_logp; a.mask = depth_mask; a.out = out_losses; a.diag = out_diag;
   hipLaunchKernelGGL(rl_loss_kernel<false>, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
   BG_CHECK_LAUNCH("bg_rl_loss_fwd");
+  if (out_diag) {
+    hipLaunchKernelGGL(rl_diag_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
+    BG_CHECK_LAUNCH("bg_rl_loss_fwd (diagnostics)");
+  }
   return BG_OK;
 }
 

@@ -347,7 +347,12 @@ int bg_disc_loss_bwd(const bg_disc_loss_shape* shape, const float* input_scores,
  * out fp32 [2] = {loss-RL-input, loss-RL-alterations}.  backward: g fp32 [2] -> d_label_logp, d_alt_logp.
  * Probabilities enter as log-probs; the clamp to [1e-6, 1-1e-6] of ReinforceLoss.py:22,46 is applied to
  * exp(logp) and its zero gradient outside the clamp is reproduced.
+ * out_diag (NULL: skipped; else one more launch) fp32 [BG_RL_DIAG_COUNT] = _calculateDebuggingStats (GeneratorLosses.py:34-81)
+ * in the reference's dict order: Rl-Loss-{A,B,C}-Input, Rl-Loss-{A,B,C}-Alt, Rl-Advantage-{A,B,C}-Input,
+ * Rl-Advantage-{A,B,C}-Alt, RL-Zone{A,B,C}-Input-Factor, RL-Zone{A,B,C}-Alt-Factor, RL-CorrectValueHeads-Factor,
+ * RL-CorrectInput-Factor - means over the reference's padded (B, 1+N, S) extent (an empty zone reports 0); no gradient.
  */
+#define BG_RL_DIAG_COUNT 20
 typedef struct {
   int B, S, N, K;
   float wA, wB, wC;
@@ -357,7 +362,7 @@ typedef struct {
 } bg_rl_loss_shape;
 int bg_rl_loss_fwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
                    const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
-                   const float* depth_mask, float* out_losses, void* stream);
+                   const float* depth_mask, float* out_losses, float* out_diag, void* stream);
 int bg_rl_loss_bwd(const bg_rl_loss_shape* shape, const float* input_scores, const float* alt_scores,
                    const float* in_head, const float* alt_head, const float* label_logp, const float* alt_logp,
                    const float* depth_mask, const float* g_losses,

@@ -34,11 +34,14 @@ def depth_mask_for(nodes, sparse_index, S):
 
 def train_forward(sd, cfg_g, cfg_d, input_ids, rules, sparse_index, noise_fn=None, n_update=9999,
                   rl=None, mle_weight=1.0, rl_weight=1.0, pred_weight=1.0, value_head_weight=0.25,
-                  separate_input_alt=True, input_loss_weight=1.0):
-    """_internalTrainForwardPass (GanSetup.py:193-258) -> (discLosses, genLosses, extras)."""
+                  separate_input_alt=True, input_loss_weight=1.0, forced_ids=None):
+    """_internalTrainForwardPass (GanSetup.py:193-258) -> (discLosses, genLosses, extras).
+    forced_ids: teacher-forced branch tokens (oracle.tree._substitute); extras["sampling_trace"] then holds, per sampling
+    call, the ids this fp32 model would have sampled and the logit margin to the forced ones."""
     rl = dict(rl or {})
     B, S = input_ids.shape
-    root, logits, probs, _ = T.multi_step_gen_forward(sd, cfg_g, input_ids, rules, sparse_index, noise_fn)
+    trace = [] if forced_ids is not None else None
+    root, logits, probs, _ = T.multi_step_gen_forward(sd, cfg_g, input_ids, rules, sparse_index, noise_fn, forced_ids=forced_ids, trace=trace)
     nodes = root.sub_nodes()
     depth_mask = depth_mask_for(nodes, sparse_index, S)
     alt_probs = torch.stack([pad_last(n.probs, S, 1e-5) for n in nodes], dim=1)
@@ -56,4 +59,4 @@ def train_forward(sd, cfg_g, cfg_d, input_ids, rules, sparse_index, noise_fn=Non
     g = L.generator_loss(input_ids, logits, probs, root.disc_pred, alt_scores, alt_probs, heads, depth_mask,
                          mle_weight=mle_weight, rl_weight=rl_weight, **rl)
     return d, g, dict(root=root, nodes=nodes, depth_mask=depth_mask, alt_scores=alt_scores, alt_probs=alt_probs,
-                      logits=logits, probs=probs)
+                      logits=logits, probs=probs, sampling_trace=trace)

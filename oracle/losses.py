@@ -108,6 +108,38 @@ def mirrored_negative_reinforce(policy_probs, advantages, zone_c, eps=1e-6):
     return (-torch.log(p) * advantages) * (1 - zone_c) + (-torch.log(-p + 1) * advantages) * zone_c
 
 
+def debugging_stats(rl_in, rl_alt, in_adv, alt_adv, zones, heads_ok, input_ok, depth_mask=None):
+    """_calculateDebuggingStats (GeneratorLosses.py:34-81).  rl_in (B,1,S-1), rl_alt (B,N,S) BEFORE the depth mask; in_adv
+    (B,1,S), alt_adv (B,N,S); zones = (A, B, C) float masks (B,1+N,S); heads_ok, input_ok (B,S).  An empty zone reports 0."""
+    def zone_mean(values, mask):
+        n = mask.sum()
+        return (values * mask).sum() / n if n > 0 else torch.zeros(())
+
+    def alt_factor(zone):                                          # zoneMaskCalculation (:49-63) on a (B,N,S) mask
+        if depth_mask is None:
+            return zone.mean()
+        den = depth_mask.sum() * zone.shape[0]
+        return (zone * depth_mask.unsqueeze(0)).sum() / den if den != 0 else torch.zeros(())
+
+    out = {}
+    names = (("Rl-", "A"), ("Rl-", "B"), ("RL-", "C"))             # the reference's own capitalisation (:67-72)
+    for (pre, z), m in zip(names, zones):
+        out[f"{pre}Loss-{z}-Input"] = zone_mean(rl_in, m[:, :1, :-1])
+    for (pre, z), m in zip(names, zones):
+        out[f"{pre}Loss-{z}-Alt"] = zone_mean(rl_alt, m[:, 1:])
+    for (pre, z), m in zip(names, zones):
+        out[f"{pre}Advantage-{z}-Input"] = zone_mean(in_adv, m[:, :1])
+    for (pre, z), m in zip(names, zones):
+        out[f"{pre}Advantage-{z}-Alt"] = zone_mean(alt_adv, m[:, 1:])
+    for z, m in zip("ABC", zones):
+        out[f"RL-Zone{z}-Input-Factor"] = m[:, :1].mean()
+    for z, m in zip("ABC", zones):
+        out[f"RL-Zone{z}-Alt-Factor"] = alt_factor(m[:, 1:])
+    out["RL-CorrectValueHeads-Factor"] = heads_ok.mean()
+    out["RL-CorrectInput-Factor"] = input_ok.mean()
+    return out
+
+
 def mle_loss(input_ids, logits):
     """_mleLossFromLogits (GeneratorLosses.py:133-137)."""
     return F.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]), input_ids[..., 1:].reshape(-1),
@@ -125,11 +157,13 @@ def generator_loss(input_ids, logits, probs, input_scores, alt_scores, alt_probs
     input_scores, alt_scores = input_scores.detach(), alt_scores.detach()
     if teacher_forcing:
         input_scores = torch.ones_like(input_scores)                                  # GeneratorLosses.py:14-16
-    in_adv, alt_adv, zone_c = dual_head_advantages(input_scores, alt_scores, heads["txtInputPreds"],
-                                                   heads["txtAlterationsPreds"], wA, wB, wC, in_policy, alt_policy)
+    in_adv, alt_adv, (zone_a, zone_b, zone_c, heads_ok, input_ok) = dual_head_advantages_full(
+        input_scores, alt_scores, heads["txtInputPreds"], heads["txtAlterationsPreds"], wA, wB, wC, in_policy, alt_policy)
     in_p = torch.gather(probs[:, :-1], -1, input_ids[:, 1:].unsqueeze(-1)).permute(0, 2, 1)
     rl_in = mirrored_negative_reinforce(in_p, in_adv[:, :, :-1], zone_c[:, :1][:, :, :-1])
     rl_alt = mirrored_negative_reinforce(alt_probs, alt_adv, zone_c[:, 1:])
+    with torch.no_grad():                                            # GeneratorLosses.py:110-112,161-162: logged, not trained on
+        out.update(debugging_stats(rl_in, rl_alt, in_adv, alt_adv, (zone_a, zone_b, zone_c), heads_ok, input_ok, depth_mask))
     if depth_mask is None:
         rl_alt = rl_alt[:, :, :-1]
         alt_loss = rl_alt.mean()

@@ -76,8 +76,23 @@ def _add_children(node, alt_ids, alt_probs):
         node.children.append(Node(alt_ids[:, i], node, node.depth + 1, beam, alt_probs[:, :, i]))
 
 
-def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=None):
-    """multiStepGenForward (MultiStepPrediction.py:243-332).  noise_fn(shape) -> exponential noise."""
+def _substitute(own, forced, row_logits, trace):
+    """Teacher forcing for precision studies (no counterpart in the reference): the tree continues from `forced`
+    (B, n, K) instead of the ids sampled here; `trace` receives both and, per entry, how far the forced token's logit lies
+    below the sampled one's in THIS model's logits (B, K, V) - the margin a lower-precision run had to overcome to pick it."""
+    forced = forced.to(own.dtype)
+    assert forced.shape == own.shape, (tuple(forced.shape), tuple(own.shape))
+    if trace is not None:
+        lg = row_logits.detach()
+        pick = lambda ids: torch.gather(lg, -1, ids.permute(0, 2, 1)).permute(0, 2, 1)
+        trace.append(dict(own=own.clone(), forced=forced.clone(), gap=pick(own) - pick(forced)))
+    return forced
+
+
+def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=None, forced_ids=None, trace=None):
+    """multiStepGenForward (MultiStepPrediction.py:243-332).  noise_fn(shape) -> exponential noise.
+    forced_ids: optional list with one (B, n, K) id tensor per sampling call, in call order (see _substitute)."""
+    forced_ids = list(forced_ids) if forced_ids is not None else None
     B, S_len = input_ids.shape
     sparse_index = torch.as_tensor(sparse_index)
     logits, probs, past = M.generator_forward(sd, cfg, input_ids)
@@ -95,15 +110,22 @@ def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=Non
     alt_p = S.alt_ids_probs(probs, alt)                                         # quirk 6: unmasked probs
     root = Node(input_ids, probs=label_p)
     root.kv = past
-    _add_children(root, alt[:, :, 1:][:, :, sparse_index], alt_p[:, sparse_index])
+    first = alt[:, :, 1:][:, :, sparse_index]
+    first_p = alt_p[:, sparse_index]
+    if forced_ids is not None:
+        first = _substitute(first, forced_ids.pop(0), logits[:, sparse_index], trace)
+        first_p = torch.gather(probs[:, sparse_index], -1, first.permute(0, 2, 1))
+    _add_children(root, first, first_p)
     for (n, t, p) in rules[1:]:
         for node in root.leaves():
             pos = (sparse_index + node.depth).unsqueeze(0).expand(B, -1)
             mask = node_mask(node, B, sparse_index, S_len)
-            _, pr, kv = M.generator_forward(sd, cfg, node.ids, position_ids=pos, textual_past=full_past(node), mask=mask)
+            lg, pr, kv = M.generator_forward(sd, cfg, node.ids, position_ids=pos, textual_past=full_past(node), mask=mask)
             labels = torch.cat((node.ids[:, :1], node.ids[:, -1:]), dim=1)
             alt, _ = sample(pr, n, labels, t, False, p)
             node.kv = kv
+            if forced_ids is not None:
+                alt = torch.cat((alt[:, :, :1], _substitute(alt[:, :, 1:], forced_ids.pop(0), lg, trace)), dim=2)
             _add_children(node, alt[:, :, 1:], S.alt_ids_probs(pr, alt))
     return root, logits, probs, masked
 

@@ -43,7 +43,9 @@ def test_fused_losses_match_reference_goldens(golden):
         setup = type("S", (), {"generatorMleLossWeight": 1.0, "generatorRlLossWeight": 1.0})()
         gl = losses.calcGeneratorLoss(setup, leaf["ids"], leaf["logits"], None, leaf["inputScores"].detach(), leaf["altScoresK"].detach(),
                                       fpd, rl, depthMask=t["depthMask"])
-        for k in ["loss-MLE", "loss-RL-input", "loss-RL-alterations", "loss-RL-combined", "loss-RL-unweightedCombined", "loss-RL", "loss"]:
+        gen_keys = [k[len(p) + 4:] for k in g.files if k.startswith(p + "gen_")]
+        assert len(gen_keys) == 27 and list(gl) == gen_keys          # the reference's dict, key for key and in its order
+        for k in gen_keys:                                            # incl. _calculateDebuggingStats (GeneratorLosses.py:34-81)
             np.testing.assert_allclose(f(gl[k]), g[p + "gen_" + k], atol=3e-6, rtol=2e-6, err_msg=f"{case} {k}")
         gg = torch.autograd.grad(gl["loss"], [leaf["logits"], leaf["altProbsK"]], allow_unused=True)
         np.testing.assert_allclose(f(gg[0]), g[p + "dLogits"], atol=1e-6, err_msg="dLogits")

@@ -85,8 +85,9 @@ def test_train_step_losses_and_grads_match_reference(golden, tag, family, schedu
             got = d[key]
             got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
             np.testing.assert_allclose(got, g[k], atol=5e-5, rtol=1e-4, err_msg=key)
-        if k.startswith("gloss::") and k[7:].startswith("loss"):
+        if k.startswith("gloss::"):            # every key, the 20 debugging stats of GeneratorLosses.py:34-81 included
             np.testing.assert_allclose(gl[k[7:]].detach().cpu().numpy(), g[k], atol=5e-5, rtol=1e-4, err_msg=k)
+    assert set(gl) == {k[7:] for k in g.files if k.startswith("gloss::")} and len(gl) == 27
     gl["loss"].backward()
     d["loss"].backward()
     params = dict(setup.named_parameters())

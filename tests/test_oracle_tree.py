@@ -70,8 +70,9 @@ def test_train_step_losses_and_grads_match_reference(golden, tag, family):
     d, gl, _ = G.train_forward(sd, cfg_g, cfg_d, ids, rules, sparse, NoiseReplay(g), rl=rl)
     for k in ["loss", "predLoss", "loss-Input", "loss-Alterations", "ValueHeadLoss", "ValueHead-InputLoss", "ValueHead-AltLoss"]:
         np.testing.assert_allclose(d[k].detach().numpy(), g["dloss::" + k], atol=1e-6, err_msg=k)
-    for k in ["loss", "loss-MLE", "loss-RL", "loss-RL-input", "loss-RL-alterations", "loss-RL-combined",
-              "loss-RL-unweightedCombined"]:
+    gen_keys = [k[7:] for k in g.files if k.startswith("gloss::")]
+    assert len(gen_keys) == 27 and set(gen_keys) == set(gl)          # incl. the 20 debugging stats (GeneratorLosses.py:34-81)
+    for k in gen_keys:
         np.testing.assert_allclose(gl[k].detach().numpy(), g["gloss::" + k], atol=2e-6, err_msg=k)
     gl["loss"].backward()
     d["loss"].backward()
