@@ -99,15 +99,19 @@ def _fresh_blas_workspaces():
 
 
 def _settle_collectives():
-    """ProcessGroupNCCL's watchdog thread polls the end events of the collectives it has not retired yet (every 100 ms) and aborts
-    the process when such a query fails - and on ROCm 7.2 hipEventQuery FAILS for an event whose stream is part of a capture in
-    progress on another thread (benchmarks/probes/event_query_during_capture.py).  The warm-up steps' collectives are finished
-    when this is called (device synchronised); give the watchdog time to see that, so that it has nothing to poll while the
-    captures run (they enqueue no collective)."""
-    import time
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and torch.cuda.is_available() and "nccl" in str(dist.get_backend()):
-        time.sleep(0.35)
+    """Before a capture: every collective this library enqueued must have completed (training.settle_collectives - the handles are
+    kept for exactly this).  They all run on RCCL's own stream (async_op=True), whose end events a capture on another stream does
+    not disturb, so ProcessGroupNCCL's watchdog - which aborts the process when an event query fails - can poll whatever it has
+    not retired yet while the captures run (training._INFLIGHT has the story and the probe).  Round 2 held the watchdog off with a
+    0.35 s sleep instead; BRANCHGAN_CAPTURE_SETTLE_MS brings a delay back for a runtime where the probe says otherwise (failure
+    signature: "Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last
+    recorded in a capturing stream", then abort)."""
+    from . import training
+    training.settle_collectives()
+    extra = float(os.environ.get("BRANCHGAN_CAPTURE_SETTLE_MS", "0"))
+    if extra > 0:
+        import time
+        time.sleep(extra / 1e3)
 
 
 class GraphedTrainStep:
@@ -279,6 +283,9 @@ class GraphedTrainStep:
     # ---- warm-up bookkeeping ------------------------------------------------------------------------------------------------
     def _snapshot(self):
         opts = (self.g_opt, self.d_opt)
+        for o in opts:               # sharded data parallelism: each rank holds the moments of its own slice only; every rank
+            if hasattr(o.optimizer, "gather_state"):       # builds the step at the same point, so the collective lines up
+                o.optimizer.gather_state()
         return {"params": [p.detach().clone() for p in self.model.parameters()],
                 "optim": [copy.deepcopy(o.optimizer.state_dict()) for o in opts],
                 "sched": [copy.deepcopy(o.scheduler.state_dict()) if o.scheduler is not None else None for o in opts]}

@@ -91,6 +91,7 @@ class ArenaAdam(torch.optim.Optimizer):
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
         self.state.clear()
+        self._moments_gathered = True     # zero everywhere is whole on every rank
 
     def refresh_weight_copies(self):
         """After parameters were changed by hand (load_state_dict, .data edits): re-round the low-precision copies."""
@@ -194,3 +195,4 @@ class ArenaAdam(torch.optim.Optimizer):
                     self.steps = int(float(st['step']))
         self._pending_state = None
         self.state.clear()
+        self._moments_gathered = True     # a loaded state dict holds every slice

@@ -83,6 +83,42 @@ class _Done:
     def wait(self):
         pass
 
+    def is_completed(self):
+        return True
+
+
+# Every device collective of this library is enqueued with async_op=True, i.e. on the process group's OWN stream, and its Work
+# handle is kept here until `settle_collectives` has seen it complete.  Why it matters: since torch 2.7 a collective with
+# async_op=False runs on the CALLER's current stream, so its end event lives on that stream; ProcessGroupNCCL's watchdog thread
+# polls the end events of every collective it has not retired, and on ROCm 7.2 hipEventQuery FAILS (hipErrorCapturedEvent) for an
+# event whose stream is capturing - the watchdog turns that into abort().  Round 2's aborted rehearsals (gpurun_out/rs_4.err)
+# were the sharded form's all-gather, then synchronous, enqueued from the stream graphs.GraphedTrainStep captures on.  Events on
+# RCCL's own stream are not affected by a capture elsewhere: benchmarks/probes/capture_collectives_probe.py polls all twelve
+# warm-up handles through the four captures without one failed query (profiles/r3_b_capture_collectives.txt).
+_INFLIGHT = []
+
+
+def _track(work):
+    if work is not None:
+        if len(_INFLIGHT) >= 64:         # a long run between captures: forget what has completed
+            _INFLIGHT[:] = [w for w in _INFLIGHT if not w.is_completed()]
+        _INFLIGHT.append(work)
+    return work or _Done()
+
+
+def settle_collectives(timeout_s=60.0):
+    """Returns once every collective this library enqueued has completed on the device (a condition, not a delay); called
+    before a stream capture begins.  The handles are dropped afterwards."""
+    import time
+    deadline = time.monotonic() + timeout_s
+    while _INFLIGHT:
+        if _INFLIGHT[-1].is_completed():
+            _INFLIGHT.pop()
+            continue
+        if time.monotonic() > deadline:
+            raise RuntimeError(f"settle_collectives: {len(_INFLIGHT)} collective(s) still running after {timeout_s:.0f} s")
+        time.sleep(0.0005)
+
 
 def _through_host(t, group):
     """gloo with GPU tensors (several ranks rehearsing on ONE GPU: tests/test_gpu_dp.py) goes through host copies made HERE:
@@ -97,7 +133,9 @@ def all_reduce_sum(t, group=None, async_op=True):
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
         return _Done()
-    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) or _Done()
+    if not async_op and t.is_cuda:
+        raise ValueError("all_reduce_sum: device collectives are enqueued with async_op=True only (see _INFLIGHT)")
+    return _track(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
 
 
 def reduce_scatter_sum(out, inp, group=None, async_op=True):
@@ -106,7 +144,9 @@ def reduce_scatter_sum(out, inp, group=None, async_op=True):
         dist.reduce_scatter_tensor(o, h, op=dist.ReduceOp.SUM, group=group)
         out.copy_(o)
         return _Done()
-    return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op) or _Done()
+    if not async_op and inp.is_cuda:
+        raise ValueError("reduce_scatter_sum: device collectives are enqueued with async_op=True only (see _INFLIGHT)")
+    return _track(dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
 
 
 def all_gather_slices(full, mine, group=None):
@@ -117,7 +157,7 @@ def all_gather_slices(full, mine, group=None):
         dist.all_gather_into_tensor(o, mine.cpu(), group=group)
         full.copy_(o)
         return
-    dist.all_gather_into_tensor(full, mine, group=group, async_op=True).wait()
+    _track(dist.all_gather_into_tensor(full, mine, group=group, async_op=True)).wait()
 
 
 class GradArena:

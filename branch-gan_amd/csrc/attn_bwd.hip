@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_dq_kernel(AttnArgs a) {
     else mma_reduce_rows_tr<DH, 0, NDT>(dq, s, k_row, lane);
   }
 
-  const int plen = valid ? a.path_len[n] : 0;
+  const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
   for (int p = 0; p < sh.max_path; ++p) {
     const bool act = p < plen;
     const int slot = act ? a.path[n * sh.max_path + p] : 0;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
       const int nt = n0 + tid;
       bool member = false;
       if (nt < sh.NQ) {                                 // every entry of the row is loaded at once (no wait on path_len first)
-        const int plen = a.path_len[nt];
+        const int plen = sh.max_path ? a.path_len[nt] : 0;
         for (int p = 0; p < sh.max_path; ++p) member |= (a.path[nt * sh.max_path + p] == slot) & (p < plen);
       }
       const unsigned long long bal = __ballot(member);

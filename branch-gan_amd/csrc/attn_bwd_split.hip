@@ -118,7 +118,7 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
   // and - before the number of key tiles is known - key tile `wave` (dropped if the tile turns out to be beyond the context).
   int ctx = valid ? a.ctx_len[kq] : 0;
   const float lse = valid ? a.lse[stat] : 0.f;
-  const int plen = valid ? a.path_len[n] : 0;
+  const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
   TileRegs<T, DH, 64> kreg, vreg;
   typename std::conditional<SL::OWN, LdsRowFrag<T, DH>, RowFrag<T, DH>>::type qf, dof;   // own tile in LDS: read where used
   float delta;

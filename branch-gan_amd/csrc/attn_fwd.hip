@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
   }
 
   // branch keys: the same branch point kq of every slot on this node's path (ancestors, then self)
-  const int plen = valid ? a.path_len[n] : 0;
+  const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
   for (int p = 0; p < sh.max_path; ++p) {
     const bool act = p < plen;
     int slot = act ? a.path[n * sh.max_path + p] : 0;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
   // ONE round of loads: context length, path, the Q tile and - before the number of key tiles is known - key tile `wave`
   int ctx = valid ? a.ctx_len[kq] : 0;
-  const int plen = valid ? a.path_len[n] : 0;
+  const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
   T* q_l = (T*)(smem + SL::STAGE_BYTES);
   TileRegs<T, DH, 256> gq;
   gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, blk.x * ATT_TILE, tid);

@@ -688,6 +688,12 @@ __global__ void topp_reset_kernel(int* todo) { todo[0] = 0; }
 // workspace and redone by the first form in a second launch of a few persistent workgroups: same results.
 #define TOPP_NOISE_EARLY 7                        // noise vectors requested before the candidate pass (registers)
 #define TOPP_REGION 768                           // list entries per wave (16 regions: 96 KB)
+// 96 KB of regions + 8 KB of histograms and lists: more static LDS than any part but gfx950 (160 KB per CU) offers.  The
+// library is written for gfx950 only (csrc/Makefile); a build for another --offload-arch stops here with a message instead of
+// failing somewhere inside the linker.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "topp_list_kernel needs the 160 KB LDS of gfx950 (MI355X): build with --offload-arch=gfx950"
+#endif
 __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int* todo) {
   __shared__ u64 big[(TOPP_THREADS / 64) * TOPP_REGION];     // level 1: 256 exponents x 16 replicas of u64 sums; then the regions
   __shared__ double e_sum[256];

@@ -178,3 +178,32 @@ def test_shape_errors():
     with pytest.raises(ValueError):
         ops.branch_attention(q, torch.randn(1, 1, 8, 64).cuda(), torch.randn(1, 1, 8, 64).cuda(),
                              torch.ones(5, dtype=torch.int32).cuda(), [q], [q])
+
+
+@pytest.mark.parametrize("dtype,Dh", [(torch.bfloat16, 64), (torch.float32, 64), (torch.bfloat16, 256), (torch.float32, 256)])
+def test_c_abi_root_pass_with_null_path_tables(dtype, Dh):
+    """include/branchgan.h lets a C-ABI caller pass NULL path / path_len when max_path == 0 (the root causal pass): every kernel
+    family behind bg_branch_attn_fwd / _bwd (key-split, query-split, one-launch and split backward, the round-1 kernels at fp32
+    Dh 256) must then leave the tables alone.  Same bits as the call with tables."""
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(21)
+    B, H, S = 1, 2, 96
+    q, k, v, go = [torch.randn(B, H, S, Dh, generator=gen).to(dtype).cuda() for _ in range(4)]
+    ld = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o_ref, lse_ref = ops.causal_attention(*ld)
+    g_ref = torch.autograd.grad(o_ref, ld, go)
+    q5 = q.unsqueeze(2)
+    ctx_len = ops.causal_ctx_len(S, S, q.device)
+    out = torch.empty((B, 1, S, H, Dh), dtype=dtype, device="cuda").permute(0, 3, 1, 2, 4)
+    lse = torch.empty((B, H, 1, S), dtype=torch.float32, device="cuda")
+    sh = ops._attn_shape(q5, k, [], 1.0 / Dh ** 0.5, 0, out)
+    ops.attn_fwd_launch(sh, q5, k, v, [], [], ctx_len, None, None, out, lse)
+    assert torch.equal(out.squeeze(2), o_ref) and torch.equal(lse.squeeze(2), lse_ref)
+    dout = torch.empty_strided(out.shape, out.stride(), dtype=dtype, device="cuda").copy_(go.unsqueeze(2))
+    dq = torch.empty((B, H, 1, S, Dh), dtype=dtype, device="cuda")
+    dk, dv, delta = torch.empty_like(k), torch.empty_like(k), torch.empty_like(lse)
+    sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq.stride()[:4]
+    ops.attn_bwd_launch(sh, q5, k, v, [], [], ctx_len, None, None, out, lse, dout, dq, dk, dv, None, None, [], [], delta)
+    torch.cuda.synchronize()
+    for got, want in zip((dq.squeeze(2), dk, dv), g_ref):
+        assert torch.equal(got, want)

@@ -55,8 +55,16 @@ def _run(rank, world, port, tmp, variant, batch=4):
     if graphed:
         step = GraphedTrainStep(model, conf, g_opt, d_opt, mine[0], 9999, rl, None, warmup=3, restore_after_warmup=False)     # 3 eager steps on batch 0, kept
         assert step._defer_d == (world > 1)
-        for i in range(2):
-            step.step(mine[1 + i], 3 + i)
+        if variant == "sharded-regraphed":
+            # a SECOND graphed step built mid-training with the default restore_after_warmup=True (what efficentTrainingLoop does at
+            # every new tree depth): its snapshot needs whole Adam moments, which a sharded step leaves sliced
+            step.step(mine[1], 3)
+            step.check_nan()
+            step = GraphedTrainStep(model, conf, g_opt, d_opt, mine[0], 9999, rl, None, warmup=2)
+            step.step(mine[2], 4)
+        else:
+            for i in range(2):
+                step.step(mine[1 + i], 3 + i)
         step.check_nan()
     elif sgd:                                          # ONE step: after it the sampled branch tokens may differ between the partitions
         training.train_step(model, mine[0], conf, g_opt, d_opt, 0, 9999, rl)
@@ -102,8 +110,10 @@ def test_two_ranks_on_one_gpu():
     and graphed: the same parameters as the all-reduce forms, and whole moments on every rank after gather_state()."""
     tmp = __import__("tempfile").mkdtemp()
     got = {}
-    for variant in ("torch-adam", "arena-adam", "graphed", "sharded", "sharded-graphed"):
+    for variant in ("torch-adam", "arena-adam", "graphed", "sharded", "sharded-graphed", "sharded-regraphed"):
         got[variant] = _two_ranks(tmp, variant)
+    for k, v in got["sharded-regraphed"].items():        # the warm-up steps of the second build were put back: nothing but steps 3, 4
+        torch.testing.assert_close(v, got["sharded-graphed"][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"regraphed {k}: {m}")
     m0 = torch.load(os.path.join(tmp, "sharded_moments_r0.pt"), weights_only=True)
     m1 = torch.load(os.path.join(tmp, "sharded_moments_r1.pt"), weights_only=True)
     assert len(m0) > 10 and all(torch.equal(m0[k], m1[k]) for k in m0) and any(bool(v.any()) for v in m0.values())
@@ -111,7 +121,7 @@ def test_two_ranks_on_one_gpu():
         assert torch.equal(v, got["arena-adam"][k]), k
     ref = got["torch-adam"]
     moved = 0.0
-    for variant in ("arena-adam", "graphed", "sharded", "sharded-graphed"):
+    for variant in ("arena-adam", "graphed", "sharded", "sharded-graphed", "sharded-regraphed"):
         for k, v in got[variant].items():
             torch.testing.assert_close(v, ref[k], rtol=1e-4, atol=1e-4, msg=lambda m: f"{variant} {k}: {m}")
     torch.manual_seed(0)

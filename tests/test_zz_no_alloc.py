@@ -67,3 +67,42 @@ def test_static_entry_without_split_and_size_limit():
     ids = torch.empty((2047, 64), dtype=torch.int64, device="cuda")
     rc = lib.bg_topn_select_static(C.ptr(big), 0, 2047, 8192, 8192, None, None, 0, None, 0, 0.0, 64, C.ptr(ids), None, C.stream_ptr())
     assert rc == 3 and b"partial items need" in lib.bg_last_error()
+
+
+def test_static_entry_runs_under_graph_capture():
+    """What the entry point exists for: callers that cannot allocate.  A hipMalloc / hipFree, a synchronisation or an allocating
+    library call inside a stream capture is an error, so the static call is captured into a HIP graph (after one eager call on
+    the device, which takes the array's address with hipGetSymbolAddress), replayed on fresh inputs and compared bit for bit
+    with the workspace entry point."""
+    lib = C.lib()
+    g = torch.Generator().manual_seed(13)
+    rows, V, n = 128, 50304, 8                                           # 8 splits per row: the partial lists are in use
+    scores = torch.randn(rows, V, generator=g).cuda()
+    ids = torch.full((rows, n), -7, dtype=torch.int64, device="cuda")
+    keys = torch.full((rows, n), -7.0, dtype=torch.float32, device="cuda")
+    assert lib.bg_topn_workspace_bytes(rows, V, n) > 0
+
+    def static_call():
+        C.check(lib.bg_topn_select_static(C.ptr(scores), C.dtype_code(scores), rows, V, scores.stride(0), None, None, 0, None, 0, 0.0, n,
+                                          C.ptr(ids), C.ptr(keys), C.stream_ptr()), "bg_topn_select_static")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        static_call()                                                    # eager: resolves the symbol address on this device
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):                           # default error mode: any allocation or sync raises
+        static_call()
+    scores.copy_(torch.randn(rows, V, generator=g))                      # new inputs at the captured addresses
+    ids.fill_(-7)
+    graph.replay()
+    torch.cuda.synchronize()
+    want_ids = torch.empty_like(ids)
+    want_keys = torch.empty_like(keys)
+    ws_bytes = lib.bg_topn_workspace_bytes(rows, V, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    C.check(lib.bg_topn_select(C.ptr(scores), C.dtype_code(scores), rows, V, scores.stride(0), None, None, 0, None, 0, 0.0, n,
+                               C.ptr(want_ids), C.ptr(want_keys), C.ptr(ws), ws_bytes, C.stream_ptr()), "bg_topn_select")
+    torch.cuda.synchronize()
+    assert torch.equal(ids, want_ids) and torch.equal(keys.view(torch.int32), want_keys.view(torch.int32))
+    assert torch.equal(ids[:, 0], scores.argmax(-1))
