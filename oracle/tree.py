@@ -9,9 +9,21 @@ from . import models as M
 from . import sampling as S
 
 
+RANDOM_TECHNIQUES = (S.RANDOM, S.EPSILON_GREEDY, S.EPSILON_SAMPLE, S.EPSILON_SAMPLE_NO_REPLACEMENT)   # SamplingStrategies.py:45-50
+
+
+def random_node_info(tech, params, n):
+    """getRandomNodesFromRule (MultiStepPrediction.py:229-235): which of a sampling call's n children are random draws."""
+    if tech not in RANDOM_TECHNIQUES:
+        return [False] * n
+    if tech == S.RANDOM:
+        return [True] * n
+    return [False] * (n - params["numRandomSamples"]) + [True] * params["numRandomSamples"]
+
+
 class Node:
-    def __init__(self, ids, parent=None, depth=0, beam=0, probs=None):
-        self.ids, self.parent, self.depth, self.beam, self.probs = ids, parent, depth, beam, probs
+    def __init__(self, ids, parent=None, depth=0, beam=0, probs=None, is_random=False):
+        self.ids, self.parent, self.depth, self.beam, self.probs, self.is_random = ids, parent, depth, beam, probs, is_random
         self.children, self.kv, self.mask = [], None, None
         self.disc_pred = self.in_value = self.alt_value = None
 
@@ -23,10 +35,11 @@ class Node:
             out.extend(c.sub_nodes())
         return out
 
-    def leaves(self):
+    def leaves(self, include_random=True):
+        """getLeaves (MultiStepPrediction.py:67-83): random children (and everything below them) are skipped on request."""
         if not self.children:
             return [self]
-        return [l for c in self.children for l in c.leaves()]
+        return [l for c in self.children if include_random or not c.is_random for l in c.leaves(include_random)]
 
 
 def depth1_mask(batch, sparse_index, S):
@@ -70,10 +83,10 @@ def full_past(node):
             for l in range(len(chain[0]))]
 
 
-def _add_children(node, alt_ids, alt_probs):
+def _add_children(node, alt_ids, alt_probs, is_random=None):
     for i in range(alt_ids.shape[1]):
         beam = i if node.parent is None else node.beam
-        node.children.append(Node(alt_ids[:, i], node, node.depth + 1, beam, alt_probs[:, :, i]))
+        node.children.append(Node(alt_ids[:, i], node, node.depth + 1, beam, alt_probs[:, :, i], bool(is_random[i]) if is_random else False))
 
 
 def _substitute(own, forced, row_logits, trace):
@@ -91,7 +104,9 @@ def _substitute(own, forced, row_logits, trace):
 
 def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=None, forced_ids=None, trace=None):
     """multiStepGenForward (MultiStepPrediction.py:243-332).  noise_fn(shape) -> exponential noise.
-    forced_ids: optional list with one (B, n, K) id tensor per sampling call, in call order (see _substitute)."""
+    forced_ids: optional list with one (B, n, K) id tensor per sampling call, in call order (see _substitute).
+    A rule is (numAlterations, technique, params) or, with the options of SamplingRule (SamplingStrategies.py:53-63),
+    (numAlterations, technique, params, {"continue_from_random": bool, "first_beam": (technique, params)})."""
     forced_ids = list(forced_ids) if forced_ids is not None else None
     B, S_len = input_ids.shape
     sparse_index = torch.as_tensor(sparse_index)
@@ -105,7 +120,7 @@ def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=Non
         return S.sample_from_generator_distribution(p, n, ids, tech, block_sampling_of_labels=block,
                                                     include_final_time_step=True, noise=noise, **params)
 
-    n0, t0, p0 = rules[0]
+    n0, t0, p0 = rules[0][:3]
     alt, masked = sample(probs, n0, input_ids, t0, True, p0)                    # quirk 5: step 1 blocks the label
     alt_p = S.alt_ids_probs(probs, alt)                                         # quirk 6: unmasked probs
     root = Node(input_ids, probs=label_p)
@@ -115,9 +130,16 @@ def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=Non
     if forced_ids is not None:
         first = _substitute(first, forced_ids.pop(0), logits[:, sparse_index], trace)
         first_p = torch.gather(probs[:, sparse_index], -1, first.permute(0, 2, 1))
-    _add_children(root, first, first_p)
-    for (n, t, p) in rules[1:]:
-        for node in root.leaves():
+    _add_children(root, first, first_p, random_node_info(t0, p0, n0))
+    for rule in rules[1:]:
+        n, t, p = rule[:3]
+        opts = rule[3] if len(rule) > 3 else {}
+        rule_n, rule_t, rule_p = n, t, p
+        for node in root.leaves(opts.get("continue_from_random", False)):      # SamplingRule's default: random leaves stop
+            n, t, p = rule_n, rule_t, rule_p
+            if node.beam == 0 and opts.get("first_beam") is not None:           # MultiStepPrediction.py:302-305
+                t, p = opts["first_beam"]
+                n = rule_n + p["numRandomSamples"]
             pos = (sparse_index + node.depth).unsqueeze(0).expand(B, -1)
             mask = node_mask(node, B, sparse_index, S_len)
             lg, pr, kv = M.generator_forward(sd, cfg, node.ids, position_ids=pos, textual_past=full_past(node), mask=mask)
@@ -126,7 +148,7 @@ def multi_step_gen_forward(sd, cfg, input_ids, rules, sparse_index, noise_fn=Non
             node.kv = kv
             if forced_ids is not None:
                 alt = torch.cat((alt[:, :, :1], _substitute(alt[:, :, 1:], forced_ids.pop(0), lg, trace)), dim=2)
-            _add_children(node, alt[:, :, 1:], S.alt_ids_probs(pr, alt))
+            _add_children(node, alt[:, :, 1:], S.alt_ids_probs(pr, alt), random_node_info(t, p, n))
     return root, logits, probs, masked
 
 

@@ -334,13 +334,28 @@ def g3_g5(family, tag, rules_spec, seed, sparse, B=2, S=12):
     out["inputIDs"], out["sparseIndex"] = ids, np.asarray(sparse, dtype=np.int64)
 
     def mk_rules():
-        return [SS.SamplingRule(a, T(t), dict(p)) for (a, t, p) in rules_spec]
+        """(numAlterations, technique, params[, options]); options: continueFromRandom, firstBeam = (technique, params)
+        (SamplingStrategies.py:53-63; used by MultiStepPrediction.py:292,302-307)."""
+        rules = []
+        for spec in rules_spec:
+            a, t, p = spec[:3]
+            o = spec[3] if len(spec) > 3 else {}
+            fb = o.get("firstBeam")
+            rules.append(SS.SamplingRule(a, T(t), dict(p), continueFromRandom=o.get("continueFromRandom", False),
+                                         firstBeamSamplingStrategy=T(fb[0]) if fb else None,
+                                         firstBeamSamplingParams=dict(fb[1]) if fb else None))
+        return rules
 
-    out["rules"] = np.asarray([[a, t] for (a, t, _) in rules_spec], dtype=np.int64)
+    out["rules"] = np.asarray([[spec[0], spec[1]] for spec in rules_spec], dtype=np.int64)
+    if any(len(spec) > 3 or spec[2] for spec in rules_spec):
+        import json
+        out["rules_json"] = np.asarray(json.dumps([list(spec) for spec in rules_spec]))
+        out["torch_seed"] = np.asarray(seed + 100)      # the random techniques draw from torch's global CPU generator
     stub = StubBuffer(seed + 7)
     SS.SAMPLE_BUFFER = stub
     sp = torch.tensor(sparse)
     # --- G3: tree pieces --------------------------------------------------------------------------
+    torch.manual_seed(seed + 100)
     root, firstPred, firstProbs, maskedProbs = MSP.multiStepGenForward(setup.generator, ids, mk_rules(), "cpu",
                                                                        sparseIndex=sp)
     nodes = dump_tree(root, "gen_", out)
@@ -359,6 +374,7 @@ def g3_g5(family, tag, rules_spec, seed, sparse, B=2, S=12):
     rl = RLM.ReinforcementLearningConfig(labelMode=RLM.ReinforcementLabelMode.ALTERATIONS_AND_INPUT_UNWEIGHTED,
                                          sectionWeightA=1, sectionWeightB=1, sectionWeightC=1.5, teacherForcing=True)
     setup.zero_grad()
+    torch.manual_seed(seed + 100)
     discLosses, genLosses = setup.trainForwardPassNoMetrics(ids, conf, 9999, collectTreeDepthData=True,
                                                             reinforcementLearningConfig=rl)
     genLosses["loss"].backward()
@@ -621,6 +637,13 @@ def main():
         return g6_schedules()
     if sys.argv[1:] == ["g7"]:
         return g7_metrics()
+    TK, NR, EG = T.TOP_K.value, T.SAMPLE_NO_REPLACEMENT.value, T.EPSILON_GREEDY.value
+    # round 3: the tree options - random children (EPSILON_GREEDY), a special rule for beam 0, random leaves that stop
+    rand_spec = [(2, TK, {}),
+                 (2, EG, {"numRandomSamples": 1}, {"firstBeam": (EG, {"numRandomSamples": 2})}),
+                 (1, TK, {}, {"continueFromRandom": False})]
+    if sys.argv[1:] == ["g35rand"]:
+        return g3_g5("neox", "neox_rand", rand_spec, 15, [0, 3, 5, 8, 10])
     g6_schedules()
     g7_metrics()
     g8_dataloader()
@@ -629,7 +652,7 @@ def main():
     g2_sampling()
     g4_losses()
     g10_boundary()
-    TK, NR = T.TOP_K.value, T.SAMPLE_NO_REPLACEMENT.value
+    g3_g5("neox", "neox_rand", rand_spec, 15, [0, 3, 5, 8, 10])
     g3_g5("neox", "neox_chain4", [(1, TK, {})] * 4, 11, [1, 3, 6, 8, 10])
     g3_g5("neox", "neox_tree211", [(2, TK, {}), (1, NR, {}), (1, TK, {})], 12, [0, 2, 5, 9])
     g3_g5("gpt2", "gpt2_chain3", [(1, TK, {})] * 3, 13, [1, 3, 6, 8, 10])

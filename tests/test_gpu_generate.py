@@ -1,8 +1,11 @@
 """Autoregressive decoding and the generated-text metrics (inference half).
 
-HF `generate` cannot run on the reference's model classes here, so the decode loop has no reference output (parity unpinned);
-it is pinned by a property: greedy decoding through the KV slots / folded text K/V emits exactly the arg-max tokens of full
-re-forwards of the growing sequence, for both model families, across a fold boundary (more than 32 new tokens).  The host
+HF `generate` cannot run on the reference's model classes here, so the decode loop has no reference OUTPUT to pin against.  It
+is anchored to the oracle instead: greedy decoding through the KV slots / folded text K/V must emit, token for token, the
+arg-max of oracle.models.lm_forward (the CPU restatement of the reference's LM forward, itself pinned by the g35 goldens)
+re-run over the growing sequence - which is what HF's greedy `generate` computes by definition - for both model families and
+across a fold boundary (more than 32 new tokens); the self-cross-entropy of Inference/GenerateTexts.py:41-78 is compared
+with the same oracle.  A second, oracle-free form of the property (re-forwards on the HIP model) stays beside it.  The host
 metrics are compared with the reference's GeneratedTextsMetric functions (tests/golden/g9_text_metrics.json)."""
 import json
 import os
@@ -58,6 +61,50 @@ def test_greedy_decode_equals_full_reforward(family):
         generate.generate(lm, prompt, max_new_tokens=4, num_beams=2)
     with pytest.raises(ValueError, match="positions"):
         generate.generate(lm, prompt, max_new_tokens=200)
+
+
+def _oracle_lm(lm, cfg):
+    from oracle import models as OM
+    sd = {k: v.detach().cpu().float() for k, v in lm.state_dict().items()}
+    ocfg = OM.LMConfig("neox" if cfg.model_type == "gpt_neox" else "gpt2", cfg.num_hidden_layers, cfg.num_attention_heads, cfg.hidden_size,
+                       cfg.vocab_size, cfg.max_position_embeddings)
+    return lambda ids: OM.lm_forward(sd, "", ocfg, ids.cpu())[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gpt2", "gpt_neox"])
+def test_greedy_decode_equals_oracle_argmax(family):
+    """GenerateTexts.py:18 (`generator.generate(...)`, greedy): token t is the arg-max of the LM's logits at position t - 1 of the
+    sequence so far.  The oracle re-forwards the growing sequence on the CPU in fp32; the cached HIP decode must agree wherever
+    the oracle's two best logits are more than 1e-3 apart (all but a handful of positions, counted)."""
+    from branchgan import configs, generate, models
+    torch.manual_seed(4)
+    cfg = configs.LMConfig(family, 211, 128, 2, 4, 128)
+    lm = models.make_lm(cfg).cuda()
+    with torch.no_grad():
+        for p in lm.parameters():
+            p.mul_(8.0) if p.dim() > 1 else None
+    forward = _oracle_lm(lm, cfg)
+    prompt = torch.randint(0, 211, (3, 9), device="cuda")
+    out = generate.generate(lm, prompt, max_new_tokens=40).cpu()
+    compared = 0
+    with torch.no_grad():
+        for t in range(9, 49):
+            logits = forward(out[:, :t])[:, -1]
+            top2 = logits.topk(2, dim=-1).values
+            decisive = (top2[:, 0] - top2[:, 1]) > 1e-3
+            assert torch.equal(out[decisive, t], logits.argmax(-1)[decisive]), (family, t)
+            compared += int(decisive.sum())
+    assert compared >= 110                                               # of 120 decoded tokens
+    # self-cross-entropy (GenerateTexts.py:41-78) of contexts + generations against the oracle's log-softmax
+    pairs = [(row[:9].tolist(), row[9:].tolist()) for row in out]
+    data = [out]                                                         # "original" continuation = the same tokens here
+    original, generated = generate.calculateSelfCrossEntropy(lm, "cuda", data, pairs)
+    with torch.no_grad():
+        lp = torch.log_softmax(forward(out), -1)
+        want = -torch.gather(lp[:, :-1], -1, out[:, 1:].unsqueeze(-1)).squeeze(-1)[:, 9:].mean(-1)
+    np.testing.assert_allclose(generated, want.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(original, want.numpy(), rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.gpu

@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("neox_chain4", "gpt_neox"), ("neox_tree211", "gpt_neox"), ("gpt2_chain3", "gpt2"), ("gpt2_tree21", "gpt2")]
+# neox_rand: random children (EPSILON_GREEDY), firstBeamSamplingStrategy / Params, continueFromRandom=False
+# (MultiStepPrediction.py:292,302-307); the random ids come from torch's global CPU generator, seeded like the capture
+CASES = [("neox_chain4", "gpt_neox"), ("neox_tree211", "gpt_neox"), ("gpt2_chain3", "gpt2"), ("gpt2_tree21", "gpt2"), ("neox_rand", "gpt_neox")]
 
 
 def _setup(g, family):
@@ -20,6 +22,16 @@ def _setup(g, family):
     setup.load_state_dict(sd, strict=True)
     setup = setup.cuda().eval()
     rules = [sampling.SamplingRule(int(a), sampling.SamplingTechniques(int(t)), {}) for a, t in g["rules"].tolist()]
+    if "rules_json" in g.files:
+        import json
+        rules = []
+        for spec in json.loads(str(g["rules_json"])):
+            o = spec[3] if len(spec) > 3 else {}
+            fb = o.get("firstBeam")
+            rules.append(sampling.SamplingRule(int(spec[0]), sampling.SamplingTechniques(int(spec[1])), dict(spec[2]),
+                                               continueFromRandom=o.get("continueFromRandom", False),
+                                               firstBeamSamplingStrategy=sampling.SamplingTechniques(int(fb[0])) if fb else None,
+                                               firstBeamSamplingParams=dict(fb[1]) if fb else None))
     ids, sparse = torch.from_numpy(g["inputIDs"]).cuda(), torch.from_numpy(g["sparseIndex"])
     noises = [torch.from_numpy(g[f"noise{i}"]) for i in range(sum(k.startswith("noise") for k in g.files))]
     calls = {"i": 0}
@@ -42,6 +54,8 @@ def test_tree_nodes_match_reference(golden, tag, family):
     from branchgan import tree
     g = golden("g35_" + tag)
     setup, conf, ids, sparse, calls = _setup(g, family)
+    if "torch_seed" in g.files:
+        torch.manual_seed(int(g["torch_seed"]))
     with torch.no_grad():
         root, firstPred, _, _ = tree.multiStepGenForward(setup.generator, ids, conf.rules, "cuda", sparseIndex=sparse,
                                                          noise_fn=setup.noise_fn, clearTreePast=False)
@@ -51,8 +65,8 @@ def test_tree_nodes_match_reference(golden, tag, family):
         for i, n in enumerate(nodes):
             assert np.array_equal(n.ids.cpu().numpy(), g[f"gen_node{i}_ids"]), (tag, i)
             np.testing.assert_allclose(n.probs.cpu().numpy(), g[f"gen_node{i}_probs"], atol=5e-6)
-            depth, beam, _, parent = g[f"gen_node{i}_meta"].tolist()
-            assert (n.depth, n.beam) == (depth, beam)
+            depth, beam, is_random, parent = g[f"gen_node{i}_meta"].tolist()
+            assert (n.depth, n.beam, int(n.isRandom)) == (depth, beam, is_random)
             assert (-1 if n.parent is root else nodes.index(n.parent)) == parent
             key = f"gen_node{i}_attmask"
             if key in g.files:                 # the arithmetic descriptor expands to the reference's mask tensor
@@ -78,6 +92,8 @@ def test_train_step_losses_and_grads_match_reference(golden, tag, family, schedu
     setup, conf, ids, sparse, calls = _setup(g, family)
     rl = configs.ReinforcementLearningConfig(labelMode=configs.ReinforcementLabelMode.ALTERATIONS_AND_INPUT_UNWEIGHTED,
                                              sectionWeightA=1, sectionWeightB=1, sectionWeightC=1.5, teacherForcing=True)
+    if "torch_seed" in g.files:
+        torch.manual_seed(int(g["torch_seed"]))
     d, gl = setup.trainForwardPassNoMetrics(ids, conf, 9999, collectTreeDepthData=True, reinforcementLearningConfig=rl)
     for k in g.files:
         if k.startswith("dloss::"):

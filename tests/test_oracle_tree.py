@@ -9,7 +9,9 @@ from oracle import gan as G
 from oracle import models as M
 from oracle import tree as T
 
-CASES = [("neox_chain4", "neox"), ("neox_tree211", "neox"), ("gpt2_chain3", "gpt2"), ("gpt2_tree21", "gpt2")]
+# neox_rand: the tree options of MultiStepPrediction.py:292,302-307 - random children (EPSILON_GREEDY draws from torch's global
+# generator, seeded like the capture), a special rule for beam 0 (firstBeamSamplingStrategy), random leaves that do not continue
+CASES = [("neox_chain4", "neox"), ("neox_tree211", "neox"), ("gpt2_chain3", "gpt2"), ("gpt2_tree21", "gpt2"), ("neox_rand", "neox")]
 
 
 class NoiseReplay:
@@ -33,6 +35,16 @@ def load_case(g, family, requires_grad=False):
     cfg_g = M.config_from_state_dict(sd, "generator.generator.", family, n_head=2)
     cfg_d = M.config_from_state_dict(sd, "discriminator.nonResidualModel.", family, n_head=1)
     rules = [(int(a), int(t), {}) for a, t in g["rules"].tolist()]
+    if "rules_json" in g.files:
+        import json
+        rules = []
+        for spec in json.loads(str(g["rules_json"])):
+            o = spec[3] if len(spec) > 3 else {}
+            opts = {"continue_from_random": o.get("continueFromRandom", False)}
+            if o.get("firstBeam"):
+                opts["first_beam"] = (int(o["firstBeam"][0]), dict(o["firstBeam"][1]))
+            rules.append((int(spec[0]), int(spec[1]), dict(spec[2]), opts))
+        torch.manual_seed(int(g["torch_seed"]))
     return sd, cfg_g, cfg_d, rules, torch.from_numpy(g["inputIDs"]), torch.from_numpy(g["sparseIndex"])
 
 
@@ -48,8 +60,8 @@ def test_tree_matches_reference(golden, tag, family):
         for i, n in enumerate(nodes):
             assert np.array_equal(n.ids.numpy(), g[f"gen_node{i}_ids"]), i
             np.testing.assert_allclose(n.probs.numpy(), g[f"gen_node{i}_probs"], atol=1e-6)
-            depth, beam, _, parent = g[f"gen_node{i}_meta"].tolist()
-            assert (n.depth, n.beam) == (depth, beam)
+            depth, beam, is_random, parent = g[f"gen_node{i}_meta"].tolist()
+            assert (n.depth, n.beam, int(n.is_random)) == (depth, beam, is_random)
             assert (-1 if n.parent is root else nodes.index(n.parent)) == parent
             key = f"gen_node{i}_attmask"
             if key in g.files:
