@@ -66,6 +66,9 @@ SIGNATURES = {
     "bg_rank_stats": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, ctypes.POINTER(c_i32), c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_branch_attn_fwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "bg_branch_attn_fwd_workspace_bytes": (c_sz, [ctypes.POINTER(AttnShape)]),
+    "bg_branch_attn_fwd_ws": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                      c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "bg_branch_attn_bwd": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                    ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, c_vp]),

@@ -241,10 +241,15 @@ ATTN_RECORD = None
 def attn_fwd_launch(sh, q, kt, vt, slots_k, slots_v, ctx_len, path, path_len, out, lse):
     """The one place bg_branch_attn_fwd is called from."""
     ka, va = _ptr_array(slots_k), _ptr_array(slots_v)
+    # few query rows against a long key range (c4's branch steps): the library splits the keys of a query tile over several
+    # workgroups when it is handed a workspace for their partial states
+    ws_bytes = C.lib().bg_branch_attn_fwd_workspace_bytes(ctypes.byref(sh))
+    ws = _workspace(ws_bytes, q.device)
 
     def launch():
-        C.check(C.lib().bg_branch_attn_fwd(ctypes.byref(sh), C.ptr(q), C.ptr(kt), C.ptr(vt), ka, va, C.ptr(ctx_len), C.ptr(path),
-                                           C.ptr(path_len), C.ptr(out), C.ptr(lse), C.stream_ptr()), "bg_branch_attn_fwd")
+        C.check(C.lib().bg_branch_attn_fwd_ws(ctypes.byref(sh), C.ptr(q), C.ptr(kt), C.ptr(vt), ka, va, C.ptr(ctx_len), C.ptr(path),
+                                              C.ptr(path_len), C.ptr(out), C.ptr(lse), C.ptr(ws), ws.numel() if ws is not None else 0,
+                                              C.stream_ptr()), "bg_branch_attn_fwd_ws")
     with _timed("branch_attn_fwd"):
         launch()
     if ATTN_RECORD is not None:

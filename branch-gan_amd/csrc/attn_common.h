@@ -42,6 +42,9 @@ struct AttnArgs {
   void* dk_slots[BG_MAX_SLOTS];
   void* dv_slots[BG_MAX_SLOTS];
   float* delta;
+  // forward, key range of a query tile split over several workgroups (attn_fwd.hip): number of splits and the partial states
+  int kv_splits;
+  float* part;
 };
 
 template <typename K>

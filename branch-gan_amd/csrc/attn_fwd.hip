@@ -164,7 +164,18 @@ template <typename T, int DH> struct SplitLds {
   static constexpr size_t BYTES = STAGE_BYTES + Q_BYTES + 64;
 };
 
-template <typename T, int DH>
+//
+// KVSPLIT (round 3): a (batch, head) with few query rows and a LONG key range - the generator's branch steps at c4: 64 queries
+// against 512 keys, B*H = 32, i.e. 64 workgroups on a 256-CU chip, each pulling 512 KB of K / V through ONE CU (a CU takes in
+// ~25 GB/s from HBM and ~70 GB/s from its L2: 8-20 us whatever the other 192 CUs do).  The text tiles of a query tile are
+// dealt to a.kv_splits workgroups (grid.x = query tiles x splits; split s takes tiles [s * per, (s + 1) * per), the branch keys
+// ride with the last split); each leaves its merged state - running max, sum and UNNORMALISED output, fp32 - in a.part, and
+// branch_attn_fwd_merge_kernel combines the splits of a tile (a second launch: 1.5 us of boundary against the 3.5 us + per
+// workgroup that a release / acquire hand-off inside one launch costs on this part, MI355X_MICROARCH.md).
+// Layout of a.part per (bh, query tile, split): [DH][32] outputs (feature-major, query on the lane) then [2][32] = max, sum.
+template <int DH> constexpr size_t fwd_part_floats() { return (size_t)(DH + 2) * ATT_TILE; }
+
+template <typename T, int DH, bool KVSPLIT = false>
 __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_fwd_split_kernel(AttnArgs a) {
   using SL = SplitLds<T, DH>;
   constexpr int NDT = DH / 32;
@@ -173,7 +184,13 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   T* k_row = (T*)(smem + wave * SL::WAVE_BYTES);
   T* v_z = k_row + SL::K_ELEMS;
-  const BlockXY blk = xcd_block();
+  BlockXY blk = xcd_block();
+  const int n_splits = KVSPLIT ? a.kv_splits : 1;
+  const int split = KVSPLIT ? blk.x % n_splits : 0;
+  if constexpr (KVSPLIT) blk.x /= n_splits;
+  // text tiles of this workgroup: [t_lo, t_lo + t_per), cut by the tile's own context below
+  const int t_per = KVSPLIT ? ((sh.S_text + ATT_TILE - 1) / ATT_TILE + n_splits - 1) / n_splits : (1 << 28);
+  const int t_lo = split * t_per;
   const int bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K;
   const int rq = blk.x * ATT_TILE + (lane & 31);
@@ -188,9 +205,9 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   TileRegs<T, DH, 256> gq;
   gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, blk.x * ATT_TILE, tid);
   TileRegs<T, DH, 64> kreg, vreg;
-  if (wave * ATT_TILE < sh.S_text) {
-    kreg.load(kt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
-    vreg.load(vt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
+  if ((t_lo + wave) * ATT_TILE < sh.S_text) {
+    kreg.load(kt, sh.t_ss, (t_lo + wave) * ATT_TILE, sh.S_text, lane);
+    vreg.load(vt, sh.t_ss, (t_lo + wave) * ATT_TILE, sh.S_text, lane);
   }
   gq.template store<true, false>(q_l, nullptr, tid);
   __syncthreads();
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   int tile_ctx = ctx;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tile_ctx = max(tile_ctx, __shfl_xor(tile_ctx, o));
-  const int ntiles = (tile_ctx + ATT_TILE - 1) / ATT_TILE;
+  const int ntiles = min((tile_ctx + ATT_TILE - 1) / ATT_TILE, KVSPLIT ? t_lo + t_per : (1 << 28));
 
   float m = -INFINITY, l = 0.f;
   f32x16 o[NDT];
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
 
-  for (int t = wave; t < ntiles; t += ATT_WAVES) {
+  for (int t = t_lo + wave; t < ntiles; t += ATT_WAVES) {
     const int kb = t * ATT_TILE;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
     kreg.template store<true, false>(k_row, nullptr, lane);
@@ -253,8 +270,8 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     else mma_reduce_rows_tr<DH, 0, NDT>(o, s, v_z, lane);
   }
 
-  // branch keys, path entries wave, wave + 4, ...
-  for (int p = wave; p < sh.max_path; p += ATT_WAVES) {
+  // branch keys, path entries wave, wave + 4, ...  (key-range split: the last split's)
+  for (int p = (!KVSPLIT || split == n_splits - 1) ? wave : sh.max_path; p < sh.max_path; p += ATT_WAVES) {
     const bool act = p < plen;
     const int slot = a.path[n * sh.max_path + p];          // in bounds for every p < max_path: no wait on path_len first
     const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     const int qi = tid & 31, grp = tid >> 5;
     const int rq2 = blk.x * ATT_TILE + qi;
     if (rq2 < R) {
-      const int n2 = rq2 / sh.K, k2 = rq2 % sh.K;
+      [[maybe_unused]] const int n2 = rq2 / sh.K, k2 = rq2 % sh.K;
       float mw[ATT_WAVES], sw[ATT_WAVES], mstar = -INFINITY, lstar = 0.f;
 #pragma unroll
       for (int w = 0; w < ATT_WAVES; ++w) {
@@ -309,6 +326,23 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
       for (int w = 0; w < ATT_WAVES; ++w) {
         sw[w] = (mw[w] == -INFINITY) ? 0.f : __expf(mw[w] - mstar);
         lstar += ml[(w * 2 + 1) * ATT_TILE + qi] * sw[w];
+      }
+      if constexpr (KVSPLIT) {
+        // this workgroup's state, unnormalised: the merge kernel scales it by exp(mstar - max over the splits)
+        const int n_qtiles = (R + ATT_TILE - 1) / ATT_TILE;
+        float* part = a.part + (((int64_t)bh * n_qtiles + blk.x) * n_splits + split) * fwd_part_floats<DH>();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < ATT_WAVES; ++w) v += mo[(w * DH + grp * PER + j) * ATT_TILE + qi] * sw[w];
+          part[(grp * PER + j) * ATT_TILE + qi] = v;
+        }
+        if (grp == 0) {
+          part[(DH + 0) * ATT_TILE + qi] = mstar;
+          part[(DH + 1) * ATT_TILE + qi] = lstar;
+        }
+        return;
       }
       const float inv = (lstar > 0.f) ? 1.f / lstar : 0.f;
       T* o_row = (T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n2 * sh.o_sn + (int64_t)k2 * sh.o_sk + grp * PER;
@@ -339,6 +373,70 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   }
 }
 
+// The splits of a query tile combined: thread -> query tid & 31, feature group tid >> 5, as in the epilogue above.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void branch_attn_fwd_merge_kernel(AttnArgs a) {
+  const bg_attn_shape& sh = a.sh;
+  const int tid = threadIdx.x, qi = tid & 31, grp = tid >> 5;
+  constexpr int PER = DH / 8;
+  const int bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  const int R = sh.NQ * sh.K, n_qtiles = (R + ATT_TILE - 1) / ATT_TILE, ns = a.kv_splits;
+  const int rq = blockIdx.x * ATT_TILE + qi;
+  if (rq >= R) return;
+  const float* part = a.part + ((int64_t)bh * n_qtiles + blockIdx.x) * ns * fwd_part_floats<DH>();
+  float mstar = -INFINITY, lstar = 0.f;
+  for (int s = 0; s < ns; ++s) mstar = fmaxf(mstar, part[s * fwd_part_floats<DH>() + (DH + 0) * ATT_TILE + qi]);
+  float acc[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+  for (int s = 0; s < ns; ++s) {
+    const float* ps = part + s * fwd_part_floats<DH>();
+    const float ms = ps[(DH + 0) * ATT_TILE + qi];
+    const float w = (ms == -INFINITY) ? 0.f : __expf(ms - mstar);
+    lstar += ps[(DH + 1) * ATT_TILE + qi] * w;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = fmaf(ps[(grp * PER + j) * ATT_TILE + qi], w, acc[j]);
+  }
+  const float inv = (lstar > 0.f) ? 1.f / lstar : 0.f;
+  const int n = rq / sh.K, k = rq % sh.K;
+  T* o_row = (T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)k * sh.o_sk + grp * PER;
+#pragma unroll
+  for (int j0 = 0; j0 < PER; j0 += 4) {
+    if constexpr (sizeof(T) == 4) {
+      f32x4 ov;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ov[j] = acc[j0 + j] * inv;
+      *(f32x4*)(o_row + j0) = ov;
+    } else {
+      bf16x4 ov;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)(acc[j0 + j] * inv);
+      *(bf16x4*)(o_row + j0) = ov;
+    }
+  }
+  if (grp == 0) a.lse[((int64_t)bh * sh.NQ + n) * sh.K + k] = (lstar > 0.f) ? mstar + logf(lstar) : -INFINITY;
+}
+
+// How many workgroups the key range of a query tile is dealt to (1 = no split, no workspace): few workgroups, many key tiles.
+// BRANCHGAN_ATTN_FWD_KVSPLIT=0 switches it off, =N forces N splits wherever the shape allows (A/B runs).
+int attn_fwd_kv_splits(const bg_attn_shape& sh) {
+  static const int forced = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_KVSPLIT"); return e ? atoi(e) : -1; }();
+  const bool fits = sh.Dh <= 128 || (sh.Dh == 256 && sh.dtype == BG_BF16);
+  const int64_t wgs = cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * sh.B * sh.H;
+  const int nk = (int)cdiv((int64_t)sh.S_text, ATT_TILE);
+  if (!fits || forced == 0 || nk < 2 * ATT_WAVES) return 1;
+  int ns = forced > 0 ? forced : (int)cdiv(256, wgs);
+  if (forced < 0 && (wgs > 128 || nk < 3 * ATT_WAVES)) return 1;
+  ns = ns < nk / ATT_WAVES ? ns : nk / ATT_WAVES;          // every split has a tile for each of its four waves
+  return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+}
+
+size_t attn_fwd_workspace_bytes(const bg_attn_shape& sh) {
+  const int ns = attn_fwd_kv_splits(sh);
+  if (ns <= 1) return 0;
+  return (size_t)sh.B * sh.H * cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * ns * (sh.Dh + 2) * ATT_TILE * sizeof(float);
+}
+
 size_t attn_fwd_lds_bytes(int dtype, int Dh) {
   if (dtype == BG_F32) return (size_t)2 * ATT_TILE * (Dh + 1) * 4 + 64;
   return (size_t)(2 * ATT_TILE * (Dh + 8)) * 2 + 64;
@@ -367,7 +465,14 @@ int check_aligned16(const void* p, const char* who, const char* name) {
 template <typename T, int DH>
 static void launch_fwd_split(const AttnArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = SplitLds<T, DH>::BYTES;
-  auto kernel = branch_attn_fwd_split_kernel<T, DH>;
+  if (a.kv_splits > 1) {
+    auto kernel = branch_attn_fwd_split_kernel<T, DH, true>;
+    set_lds_limit(kernel, lds);
+    hipLaunchKernelGGL(kernel, dim3(grid.x * a.kv_splits, grid.y), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((branch_attn_fwd_merge_kernel<T, DH>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  auto kernel = branch_attn_fwd_split_kernel<T, DH, false>;
   set_lds_limit(kernel, lds);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
 }
@@ -385,7 +490,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
   // Dh 256: the four waves' K / V tiles + the Q tile fit the 160 KB of LDS in bf16 only (152 KB; fp32 would need 280 KB)
   static const bool split_256 = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_SPLIT_256"); return !(e && e[0] == '0'); }();
   const bool fits = sh.Dh <= 128 || (sh.Dh == 256 && sizeof(T) == 2 && split_256);
-  const bool split = fits && (all_split || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
+  const bool split = fits && (all_split || a.kv_splits > 1 || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
   if (split) {
     switch (sh.Dh) {
       case 32: launch_fwd_split<T, 32>(a, grid_split, st); break;
@@ -413,9 +518,21 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
 
 using namespace bg;
 
+extern "C" size_t bg_branch_attn_fwd_workspace_bytes(const bg_attn_shape* shape) {
+  if (!shape || validate_attn_shape(shape, "bg_branch_attn_fwd_workspace_bytes")) return 0;
+  return attn_fwd_workspace_bytes(*shape);
+}
+
 extern "C" int bg_branch_attn_fwd(const bg_attn_shape* shape, const void* q, const void* k_text, const void* v_text,
                                   const void* const* k_slots, const void* const* v_slots, const int32_t* ctx_len,
                                   const int32_t* path, const int32_t* path_len, void* out, float* lse, void* stream) {
+  return bg_branch_attn_fwd_ws(shape, q, k_text, v_text, k_slots, v_slots, ctx_len, path, path_len, out, lse, nullptr, 0, stream);
+}
+
+extern "C" int bg_branch_attn_fwd_ws(const bg_attn_shape* shape, const void* q, const void* k_text, const void* v_text,
+                                     const void* const* k_slots, const void* const* v_slots, const int32_t* ctx_len,
+                                     const int32_t* path, const int32_t* path_len, void* out, float* lse, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   const char* who = "bg_branch_attn_fwd";
   if (int e = validate_attn_shape(shape, who)) return e;
   if (int e = check_aligned16(q, who, "q")) return e;
@@ -431,6 +548,14 @@ extern "C" int bg_branch_attn_fwd(const bg_attn_shape* shape, const void* q, con
   a.sh = *shape;
   a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
   a.out = out; a.lse = lse;
+  a.kv_splits = 1;
+  if (workspace) {                                       // enough workspace: the key range of a query tile may be split
+    const size_t need = attn_fwd_workspace_bytes(*shape);
+    if (need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
+      a.kv_splits = attn_fwd_kv_splits(*shape);
+      a.part = (float*)workspace;
+    }
+  }
   for (int i = 0; i < shape->n_slots; ++i) {
     if (int e = check_aligned16(k_slots[i], who, "k_slots[i]")) return e;
     if (int e = check_aligned16(v_slots[i], who, "v_slots[i]")) return e;

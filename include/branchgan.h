@@ -175,6 +175,19 @@ int bg_branch_attn_fwd(const bg_attn_shape* shape,
                        const int32_t* ctx_len, const int32_t* path, const int32_t* path_len,
                        void* out, float* lse, void* stream);
 
+/* The same call with a caller workspace (same reference lines as bg_branch_attn_fwd).  With few query rows per (batch, head)
+ * and a long key range - a generator branch step at seq 512: 64 queries against 512 keys - a launch has fewer workgroups than
+ * the chip has CUs and each pulls the whole K / V of its head through one CU.  Given `workspace` (16-byte aligned, at least
+ * bg_branch_attn_fwd_workspace_bytes(shape) bytes; that is 0 when the shape is not split) the key range of a query tile is
+ * dealt to several workgroups whose partial (max, sum, output) states meet in the workspace and are combined by a second
+ * kernel on the same stream.  Same results up to fp32 summation order; NULL / too small a workspace = bg_branch_attn_fwd. */
+size_t bg_branch_attn_fwd_workspace_bytes(const bg_attn_shape* shape);
+int bg_branch_attn_fwd_ws(const bg_attn_shape* shape,
+                          const void* q, const void* k_text, const void* v_text,
+                          const void* const* k_slots, const void* const* v_slots,   /* host arrays */
+                          const int32_t* ctx_len, const int32_t* path, const int32_t* path_len,
+                          void* out, float* lse, void* workspace, size_t workspace_bytes, void* stream);
+
 int bg_branch_attn_bwd(const bg_attn_shape* shape,
                        const void* q, const void* k_text, const void* v_text,
                        const void* const* k_slots, const void* const* v_slots,   /* host arrays */

@@ -68,6 +68,7 @@ def test_golden_forward_backward_fp32(golden):
 CASES = [  # B, H, Dh, S, K, depth
     (2, 3, 64, 256, 32, 4), (1, 2, 128, 130, 40, 2), (2, 2, 32, 70, 33, 3), (1, 1, 256, 96, 64, 2), (1, 12, 64, 512, 64, 8),
     (2, 2, 256, 300, 48, 3),        # Dh 256 over ten key tiles with a ragged last one: in bf16 the key-split forward (round 2)
+    (1, 4, 256, 512, 64, 4),        # c4's branch step: 8 workgroups x 16 key tiles - the key range split over 4 workgroups (round 3)
 ]
 
 
@@ -207,3 +208,38 @@ def test_c_abi_root_pass_with_null_path_tables(dtype, Dh):
     torch.cuda.synchronize()
     for got, want in zip((dq.squeeze(2), dk, dv), g_ref):
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype,Dh,B,H", [(torch.bfloat16, 256, 4, 8), (torch.float32, 64, 1, 12), (torch.bfloat16, 64, 2, 3)])
+def test_key_range_split_forward_equals_unsplit(dtype, Dh, B, H):
+    """bg_branch_attn_fwd_ws with a workspace deals the key tiles of a query tile to several workgroups and merges their
+    (max, sum, output) states in a second kernel; without one it is bg_branch_attn_fwd.  Same attention, regrouped sums:
+    outputs and lse agree to summation order, at c4's branch-step shape (B 4, H 8, Dh 256, K 64, S 512, 3 ancestor slots)."""
+    import ctypes
+    from branchgan import _capi as C, ops
+    gen = torch.Generator().manual_seed(31)
+    K, S, n_anc = 64, 512, 3
+    mk = lambda *s: torch.randn(*s, generator=gen).to(dtype).cuda()
+    q = mk(B, H, 1, K, Dh)
+    kt, vt = mk(B, H, S, Dh), mk(B, H, S, Dh)
+    ks, vs = [mk(B, H, K, Dh) for _ in range(n_anc + 1)], [mk(B, H, K, Dh) for _ in range(n_anc + 1)]
+    sparse = np.sort(np.random.RandomState(7).choice(S - 1, K, replace=False))
+    ctx_len = (torch.as_tensor(sparse) + 1).int().cuda()
+    path, path_len, max_path = ops.path_tables([list(range(n_anc + 1))], q.device)
+    results = []
+    for use_ws in (False, True):
+        out = torch.empty((B, 1, K, H, Dh), dtype=dtype, device="cuda").permute(0, 3, 1, 2, 4)
+        lse = torch.empty((B, H, 1, K), dtype=torch.float32, device="cuda")
+        sh = ops._attn_shape(q, kt, ks, 1.0 / math.sqrt(Dh), max_path, out)
+        need = C.lib().bg_branch_attn_fwd_workspace_bytes(ctypes.byref(sh))
+        assert need > 0, "this shape is meant to take the key-range split"
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda") if use_ws else None
+        C.check(C.lib().bg_branch_attn_fwd_ws(ctypes.byref(sh), C.ptr(q), C.ptr(kt), C.ptr(vt), ops._ptr_array(ks), ops._ptr_array(vs),
+                                              C.ptr(ctx_len), C.ptr(path), C.ptr(path_len), C.ptr(out), C.ptr(lse), C.ptr(ws), need if use_ws else 0,
+                                              C.stream_ptr()), "bg_branch_attn_fwd_ws")
+        torch.cuda.synchronize()
+        results.append((out.float().cpu(), lse.cpu()))
+    (o0, l0), (o1, l1) = results
+    tol = 2e-6 if dtype == torch.float32 else 1.6e-2          # bf16: one rounding of the output, at most one ulp apart
+    np.testing.assert_allclose(o1.numpy(), o0.numpy(), atol=tol)
+    np.testing.assert_allclose(l1.numpy(), l0.numpy(), atol=2e-6, rtol=1e-6)
