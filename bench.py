@@ -58,7 +58,13 @@ def zipf_ids(n, S, V, seed):
 def build(workload, device, seed=0):
     from branchgan import configs, gan, sampling, training
     torch.manual_seed(seed)          # identical initial weights on every rank
-    model = gan.GannSetup(workload["gen"], workload["disc"], mleLossWeight=1, rlLossWeight=1, discValueHeadLossWeight=0.25, device=device).to(device)
+    lm = lambda name: configs.LMConfig.from_any(name)
+    if workload.get("dropout"):      # --dropout P: the stock GPT-2 rates are 0.1 (attention probabilities: inside the attention kernels)
+        import dataclasses
+        p = workload["dropout"]
+        lm = lambda name: dataclasses.replace(configs.LMConfig.from_any(name), attn_pdrop=p, resid_pdrop=p,
+                                              **({"embd_pdrop": p} if configs.LMConfig.from_any(name).model_type != "gpt_neox" else {}))
+    model = gan.GannSetup(lm(workload["gen"]), lm(workload["disc"]), mleLossWeight=1, rlLossWeight=1, discValueHeadLossWeight=0.25, device=device).to(device)
     rules = [sampling.SamplingRule(1, sampling.SamplingTechniques.TOP_K, {}) for _ in range(workload["D"])]
     rank = int(os.environ.get("RANK", "0"))
     conf = configs.SamplingConfig(rules, includeAllMultiStepSamplesForDisc=True, numSampleSequences=workload["K"], seed=1234 + rank)
@@ -358,6 +364,8 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the secondary fp32 timing of the same workload")
     ap.add_argument("--no-rooflines", action="store_true", help="timed steps only: no replay of the attention launch mix (a clean kernel trace under rocprofv3)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--dropout", type=float, default=0.0, help="attention / residual / embedding dropout rate of both models (the default "
+                    "workload has none, like every parity run; stock GPT-2 configs carry 0.1)")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="hipBLASLt default heuristics instead of the recorded TunableOp choices")
     args = ap.parse_args()
     if os.environ.get("BRANCHGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
@@ -380,6 +388,9 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
+    if args.dropout:
+        wl["dropout"] = args.dropout
+        wl["name"] += f", dropout {args.dropout}"
     V = configs.LMConfig.from_any(wl["gen"]).vocab_size
     B, S = wl["B"], wl["S"]
     n_batches = 16

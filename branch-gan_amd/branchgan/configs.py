@@ -29,7 +29,7 @@ class LMConfig:
     scale_attn_weights: bool = True
     scale_attn_by_inverse_layer_idx: bool = False
     initializer_range: float = 0.02
-    attn_pdrop: float = 0.0          # the fused attention kernel has no dropout: must stay 0
+    attn_pdrop: float = 0.0          # dropout on the attention probabilities: inside the attention kernels (Dh <= 128)
     resid_pdrop: float = 0.0
     embd_pdrop: float = 0.0
 

@@ -951,15 +951,16 @@ def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True, out_for=Non
 # ---------------------------------------------------------------------------------------------------------------------
 # attention on the packed QKV projection
 # ---------------------------------------------------------------------------------------------------------------------
-def _attn_fwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse):
+def _attn_fwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, drop=None):
     path, path_len, max_path = ops.path_tables(paths, q5.device)
-    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5, drop)
     ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
 
 
-def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv, dkt_in=None, dvt_in=None):
+def _attn_bwd_call(q5, kt, vt, slots_k, slots_v, ctx_len, paths, scale, o5, lse, do5, dq5, dkt, dvt, dsk, dsv, dkt_in=None, dvt_in=None,
+                   drop=None):
     path, path_len, max_path = ops.path_tables(paths, q5.device)
-    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+    sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5, drop)
     sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
     delta = torch.empty_like(lse)
     ops.attn_bwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse, do5, dq5, dkt, dvt, dkt_in, dvt_in, dsk, dsv, delta)
@@ -987,13 +988,14 @@ class _MergedTreeAttention(torch.autograd.Function):
         lse_t = torch.empty((B, H, N, K), dtype=torch.float32, device=qkv.device)
         kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
         kt, vt = kview[:, :, :S], vview[:, :, :S]
+        drops = (ops.drop_descriptor(spec.get("p_drop")), ops.drop_descriptor(spec.get("p_drop")))     # root rows, tree rows
         _attn_fwd_call(_heads_first(qkv[:, :S, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, qkv.device), [[]], spec["scale"],
-                       _heads_first(att[:, :S], 1, S), lse_r)
+                       _heads_first(att[:, :S], 1, S), lse_r, drops[0])
         own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
         _attn_fwd_call(_heads_first(qkv[:, S:, 0], N, K), kt, vt, own(kview), own(vview), spec["ctx_len"], spec["paths"], spec["scale"],
-                       _heads_first(att[:, S:], N, K), lse_t)
+                       _heads_first(att[:, S:], N, K), lse_t, drops[1])
         ctx.save_for_backward(qkv, att, lse_r, lse_t, spec["ctx_len"])
-        ctx.meta = (S, N, K, spec["scale"], spec["paths"])
+        ctx.meta = (S, N, K, spec["scale"], spec["paths"], drops)
         ctx.qkv_from = spec.get("qkv_from")
         ctx.set_materialize_grads(False)
         return att.view(B, T, H * Dh), kview, vview
@@ -1001,7 +1003,7 @@ class _MergedTreeAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, datt, dk_out, dv_out):
         qkv, att, lse_r, lse_t, ctx_len = ctx.saved_tensors
-        S, N, K, scale, paths = ctx.meta
+        S, N, K, scale, paths, drops = ctx.meta
         B, T, _, H, Dh = qkv.shape
         dqkv = _dqkv_buffer(qkv, ctx.qkv_from)
         if datt is None:
@@ -1012,12 +1014,13 @@ class _MergedTreeAttention(torch.autograd.Function):
         kt, vt = kview[:, :, :S], vview[:, :, :S]
         _attn_bwd_call(_heads_first(qkv[:, :S, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, qkv.device), [[]], scale,
                        _heads_first(att[:, :S], 1, S), lse_r, _heads_first(do[:, :S], 1, S), _heads_first(dqkv[:, :S, 0], 1, S),
-                       dkview[:, :, :S], dvview[:, :, :S], [], [])
+                       dkview[:, :, :S], dvview[:, :, :S], [], [], drop=drops[0])
         own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
         _attn_bwd_call(_heads_first(qkv[:, S:, 0], N, K), kt, vt, own(kview), own(vview), ctx_len, paths, scale,
                        _heads_first(att[:, S:], N, K), lse_t, _heads_first(do[:, S:], N, K), _heads_first(dqkv[:, S:, 0], N, K),
                        dkview[:, :, :S], dvview[:, :, :S], own(dkview), own(dvview),
-                       dkt_in=dkview[:, :, :S], dvt_in=dvview[:, :, :S])     # the tree rows' share of the text dK / dV: added in the kernel
+                       dkt_in=dkview[:, :, :S], dvt_in=dvview[:, :, :S],     # the tree rows' share of the text dK / dV: added in the kernel
+                       drop=drops[1])
         if dk_out is not None:
             dkview.add_(dk_out)
         if dv_out is not None:
@@ -1061,17 +1064,18 @@ class _PackedAttention(torch.autograd.Function):
                 raise NotImplementedError("ancestor KV slots must share the packed-QKV layout of the new tokens")
             slots_k, slots_v = anc_k + own_k, anc_v + own_v
         path, path_len, max_path = ops.path_tables(paths, qkv.device)
-        sh = ops._attn_shape(q5, kt, slots_k, spec["scale"], max_path, o5)
+        drop = ops.drop_descriptor(spec.get("p_drop"))
+        sh = ops._attn_shape(q5, kt, slots_k, spec["scale"], max_path, o5, drop)
         ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
         ctx.save_for_backward(qkv, att, lse, ctx_len, path, path_len, *([] if root else [kt, vt]), *anc_k, *anc_v)
-        ctx.meta = (root, NQ, K, n_anc, spec["scale"], max_path)
+        ctx.meta = (root, NQ, K, n_anc, spec["scale"], max_path, drop)
         ctx.qkv_from = spec.get("qkv_from")
         ctx.set_materialize_grads(False)
         return att.view(B, T, E), kview, vview
 
     @staticmethod
     def backward(ctx, datt, dk_out, dv_out):
-        root, NQ, K, n_anc, scale, max_path = ctx.meta
+        root, NQ, K, n_anc, scale, max_path, drop = ctx.meta
         saved = ctx.saved_tensors
         qkv, att, lse, ctx_len, path, path_len = saved[:6]
         rest = list(saved[6:])
@@ -1120,7 +1124,7 @@ class _PackedAttention(torch.autograd.Function):
             slots_k, slots_v = list(anc_k) + own(kview), list(anc_v) + own(vview)
             dsk, dsv = d_anc_k + own(dkview), d_anc_v + own(dvview)
         delta = torch.empty_like(lse)
-        sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5)
+        sh = ops._attn_shape(q5, kt, slots_k, scale, max_path, o5, drop)
         sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq5.stride()[:4]
         ops.attn_bwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse, do5, dq5, dkt, dvt, dk_in, dv_in, dsk, dsv, delta)
         if dk_out is not None:      # what the descendants' attention sent back to this node's keys / values
@@ -1141,12 +1145,13 @@ def _dqkv_buffer(qkv, qkv_from):
     return t.view(qkv.shape) if t is not None else torch.empty_like(qkv)
 
 
-def packed_attention(qkv, lp, scale, out_for=None, qkv_from=None):
+def packed_attention(qkv, lp, scale, out_for=None, qkv_from=None, p_drop=0.0):
     """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views).
     out_for: the weight of the projection that reads att; qkv_from: the weight of the projection that produced qkv (see layer_norm /
     add_layer_norm)."""
     B, T, _, H, Dh = qkv.shape
-    extra = {"att_buf": _x_slab_for(out_for, B * T, H * Dh, qkv.dtype, qkv.device), "qkv_from": _pass_of(qkv_from, qkv.device)}
+    extra = {"att_buf": _x_slab_for(out_for, B * T, H * Dh, qkv.dtype, qkv.device), "qkv_from": _pass_of(qkv_from, qkv.device),
+             "p_drop": p_drop}
     if lp is None:
         att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale), **extra})
     elif getattr(lp, "merged_text", 0):

@@ -5,6 +5,7 @@ import math
 import torch
 
 from . import losses as Losses
+from . import models, ops
 from . import tree as MultiStepPrediction
 from .configs import LMConfig, ReinforcementLearningConfig
 from .models import NonResidualDiscriminatorWithDualValueHeads, NonResidualGenerator, strip_reference_buffers
@@ -48,6 +49,12 @@ class GannSetup(torch.nn.Module):
         """The generator's half of the forward pass (GanSetup.py:140-150 multiStepGenForward): root pass, branch sampling and
         the branch log-probabilities.  It touches no discriminator weight, so a caller may run it while the discriminator's
         optimizer step of the previous train step is still in flight (graphs.GraphedTrainStep does)."""
+        if models.dropout_active(self.generator) or models.dropout_active(self.discriminator) or \
+                any(r.samplingParams.get('dropoutRate') for r in samplingConf.rules):
+            # The attention-dropout masks are a function of a device-side step counter: advanced by a launch of its own at the
+            # head of the step (this method is the first thing every step runs, also when its parts are captured as separate
+            # graphs), so that a captured step draws fresh masks on every replay and backward sees the forward's masks.
+            ops.dropout_advance(self.generatorDevice)
         sparseIndex = samplingConf.getSparseIndex(inputIDs, self.generatorDevice)
         return MultiStepPrediction.multiStepGenForward(
             self.generator, inputIDs, samplingConf.rules, self.generatorDevice, sparseIndex=sparseIndex, clearTreePast=True,

@@ -78,35 +78,45 @@ def _legacy_layer_past(layer_past, mask, K, device):
                            paths=[list(range(n_anc + 1))], n_query_nodes=1)
 
 
-def branch_attention_core(q, k, v, lp, scale, return_weights=False):
+def branch_attention_core(q, k, v, lp, scale, return_weights=False, p_drop=0.0):
     """q, k, v (B,H,NQ*K,Dh) of the new tokens; lp = layer view of a BranchPast.  -> (B,H,NQ*K,Dh), and with return_weights
     the softmax weights the reference materialises ((B,H,K,C+1) for one query node, (B,H,NQ,K,W) for several), rebuilt by
-    bg_branch_attn_weights from the forward's log-sum-exp."""
+    bg_branch_attn_weights from the forward's log-sum-exp.  p_drop: dropout on the attention probabilities, inside the
+    kernel (the weights handed out are then the ones after dropout, as in the reference)."""
     NQ = lp.n_query_nodes
     K = q.shape[2] // NQ
     q5, k5, v5 = q.unflatten(2, (NQ, K)), k.unflatten(2, (NQ, K)), v.unflatten(2, (NQ, K))
     anc_k = [a[0] for a in lp.ancestors]
+    drop = ops.drop_descriptor(p_drop)
     out, lse = ops.branch_attention(q5, lp.text[0], lp.text[1], lp.ctx_len, anc_k, [a[1] for a in lp.ancestors],
-                                    paths=lp.paths, scale=scale, own_k=k5, own_v=v5)
+                                    paths=lp.paths, scale=scale, own_k=k5, own_v=v5, drop=drop)
     if not return_weights:
         return out.flatten(2, 3)
-    w = ops.branch_attention_weights(q5, lp.text[0], lp.ctx_len, anc_k, lp.paths, scale, lse, own_k=k5).to(v.dtype)
+    w = ops.branch_attention_weights(q5, lp.text[0], lp.ctx_len, anc_k, lp.paths, scale, lse, own_k=k5, drop=drop).to(v.dtype)
     return out.flatten(2, 3), (w[:, :, 0] if NQ == 1 else w)
 
 
-def causal_attention_core(q, k, v, scale, return_weights=False):
+def causal_attention_core(q, k, v, scale, return_weights=False, p_drop=0.0):
     """Root causal pass (+ its (B,H,T,S) weights on request)."""
-    out, lse = ops.causal_attention(q, k, v, scale=scale)
+    drop = ops.drop_descriptor(p_drop)
+    out, lse = ops.causal_attention(q, k, v, scale=scale, drop=drop)
     if not return_weights:
         return out, None
     ctx = ops.causal_ctx_len(q.shape[2], k.shape[2], q.device)
-    return out, ops.branch_attention_weights(q, k, ctx, [], [[]], scale, lse).to(v.dtype)
+    return out, ops.branch_attention_weights(q, k, ctx, [], [[]], scale, lse, drop=drop).to(v.dtype)
 
 
-def _check_no_attn_dropout(p):
-    if p:
-        raise NotImplementedError("attention-probability dropout is not available inside the fused attention kernel: "
-                                  "use attn_pdrop / attention_dropout = 0 (as every parity run does)")
+def dropout_active(model, dropoutRate=None):
+    """Does a forward of `model` (an LM of either family, or a wrapper holding one) draw dropout masks?  GPT-2: the embedding,
+    attention-probability and attention-output dropouts are always on (F.dropout without a training flag, quirk 1) at
+    dropoutRate or the config's rates; NeoX: nn.Dropout modules, i.e. in training mode only, dropoutRate ignored."""
+    lm = next((m for m in model.modules() if isinstance(m, _LMBase) and hasattr(m, "_fused_family")), None)
+    if lm is None:
+        return False
+    cfg = lm.config
+    if lm._fused_family == "gpt2":
+        return bool(dropoutRate or cfg.attn_pdrop or cfg.embd_pdrop or cfg.resid_pdrop)
+    return bool(lm.training and (cfg.attn_pdrop or cfg.resid_pdrop))
 
 
 _rope_cache = {}
@@ -151,7 +161,7 @@ class NeoXNonResidualAttention(nn.Module):
         self.hidden_size = config.hidden_size
         self.head_size = config.head_dim
         self.rotary_ndims = config.rotary_ndims
-        _check_no_attn_dropout(config.attn_pdrop)
+        self.attention_dropout = config.attn_pdrop      # nn.Dropout(config.attention_dropout) in the reference (:31): training mode only
         inv_freq = 1.0 / (config.rotary_emb_base ** (torch.arange(0, self.rotary_ndims, 2).float() / self.rotary_ndims))
         self.rotary_emb = nn.Module()
         self.rotary_emb.register_buffer("inv_freq", inv_freq)
@@ -166,9 +176,13 @@ class NeoXNonResidualAttention(nn.Module):
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported on the fused path")
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
+        p = self._p_drop()
         if output_attentions:
-            return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, return_weights=True)
-        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor), None
+            return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, return_weights=True, p_drop=p)
+        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, p_drop=p), None
+
+    def _p_drop(self):
+        return self.attention_dropout if self.training else 0.0
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, head_mask=None, layer_past=None,
                 use_cache=False, output_attentions=False, isNonResidual=False, textualPast=None, customCasualMask=None):
@@ -184,11 +198,11 @@ class NeoXNonResidualAttention(nn.Module):
         weights = None
         if isNonResidual:
             lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
-            attn_output = branch_attention_core(query, key, value, lp, scale, return_weights=output_attentions)
+            attn_output = branch_attention_core(query, key, value, lp, scale, return_weights=output_attentions, p_drop=self._p_drop())
             if output_attentions:
                 attn_output, weights = attn_output
         else:
-            attn_output, weights = causal_attention_core(query, key, value, scale, return_weights=output_attentions)
+            attn_output, weights = causal_attention_core(query, key, value, scale, return_weights=output_attentions, p_drop=self._p_drop())
         attn_output = attn_output.permute(0, 2, 1, 3).reshape(B, T, self.hidden_size)
         attn_output = self.dense(attn_output)
         outputs = (attn_output, present)
@@ -209,9 +223,9 @@ def _neox_fused_attention(at, h1, pos, dtype, lp):
                                           grad_buffer=fused.dy_buffer_of(at.query_key_value.weight, qkv.device))
     scale = 1.0 / at.norm_factor
     if lp is not None:
-        out = branch_attention_core(query, key, value, lp, scale)
+        out = branch_attention_core(query, key, value, lp, scale, p_drop=at._p_drop())
     else:
-        out, _ = ops.causal_attention(query, key, value, scale=scale)
+        out, _ = ops.causal_attention(query, key, value, scale=scale, drop=ops.drop_descriptor(at._p_drop()))
     out = out.permute(0, 2, 1, 3).reshape(B, T, at.hidden_size)        # (into the x stack by copy_: autograd's CopySlices costs more than the stack copy)
     return fused.linear(out, at.dense.weight, at.dense.bias, "oi", dtype), (key, value)
 
@@ -267,7 +281,7 @@ class GPTNeoXLayer(nn.Module):
             a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
             g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
             m = fused.linear(g, down_w, self.mlp.dense_4h_to_h.bias, "oi", dtype)
-            return x1, (a, m), present
+            return x1, (self._drop(a), self._drop(m)), present
         if delta is None:
             x1, h1 = x, fused.layer_norm(x, self.input_layernorm, dtype, out_for=qkv_w)
         elif isinstance(delta, tuple):
@@ -275,10 +289,20 @@ class GPTNeoXLayer(nn.Module):
         else:
             x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype, out_for=qkv_w)
         a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
-        x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias, out_for=up_w,
-                                      delta_from=self.attention.dense.weight)
+        if self.drops():      # a dropout between the projection and the residual add: the LayerNorm backward's shortcuts do not apply
+            x2, h2 = fused.add_layer_norm(x1, self._drop(a), self.post_attention_layernorm, dtype, out_for=up_w)
+        else:
+            x2, h2 = fused.add_layer_norm(x1, a, self.post_attention_layernorm, dtype, self.attention.dense.bias, out_for=up_w,
+                                          delta_from=self.attention.dense.weight)
         g = fused.linear(h2, up_w, self.mlp.dense_h_to_4h.bias, "oi", dtype, act="gelu", out_for=down_w)
-        return x2, fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype), present
+        return x2, self._drop(fused.linear(g, self.mlp.dense_4h_to_h.weight, self.mlp.dense_4h_to_h.bias, "oi", dtype)), present
+
+    def drops(self):
+        """post_attention_dropout / post_mlp_dropout (NeoXNonResidualBase.py:79-80,110-125) are active."""
+        return bool(self.hidden_dropout and self.training)
+
+    def _drop(self, t):
+        return F.dropout(t, self.hidden_dropout, True) if self.drops() else t
 
 
 def strip_reference_buffers(state_dict):
@@ -361,7 +385,8 @@ def _layer_past(textualPast, i):
 
 def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate=None):
     """The fused block path (branchgan.fused) covers the training hot path: fp32 parameters on the GPU (bf16 compute comes
-    from autocast), no dropout, engine-form past.  Everything else runs module by module."""
+    from autocast), engine-form past; dropout on the attention probabilities runs inside the attention kernels, the residual
+    / embedding dropouts as ATen ops between the fused pieces.  Everything else runs module by module."""
     ok = _fused_covers(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate)
     if not ok:
         fused.module_path_forwards += 1         # graphs.py: a step with module-by-module forwards is not replayed side by side
@@ -376,7 +401,7 @@ def _fused_covers(model, input_ids, textualPast, customCasualMask, output_hidden
         return False
     if not hasattr(model, "_fused_family"):
         return False
-    if dropoutRate or cfg.resid_pdrop or cfg.embd_pdrop or cfg.attn_pdrop:
+    if (dropoutRate or cfg.attn_pdrop) and cfg.head_dim > 128:      # dropout inside the attention kernels: Dh <= 128
         return False
     if not fused.supported_width(cfg.hidden_size) or cfg.head_dim not in (32, 64, 128, 256):
         return False
@@ -411,11 +436,13 @@ class GPTNeoXForCausalLM(_LMBase):
             pos = pos.contiguous()          # once, not per layer (an expanded view otherwise)
             with torch.autocast("cuda", enabled=False):
                 x, delta, presents = fused.embedding(input_ids, None, self.gpt_neox.embed_in.weight), None, []
+                if self.config.resid_pdrop and self.training:       # emb_dropout (NeoXNonResidualBase.py:142,239)
+                    x = F.dropout(x, self.config.resid_pdrop, True)
                 delta_from = None
                 for i, layer in enumerate(self.gpt_neox.layers):
                     x, delta, present = layer.fused_forward(x, delta, dtype, pos, _layer_past(textualPast, i) if branch else None,
                                                             delta_from)
-                    delta_from = layer.attention.dense.weight if layer.use_parallel_residual else None
+                    delta_from = layer.attention.dense.weight if layer.use_parallel_residual and not layer.drops() else None
                     presents.append(present)
                 if isinstance(delta, tuple):
                     _, y = fused.add_layer_norm(x, delta[0], self.gpt_neox.final_layer_norm, dtype, delta_b=delta[1], delta_from=delta_from)
@@ -475,16 +502,24 @@ class GPT2NonResidualAttention(nn.Module):
         s = 1.0 / math.sqrt(self.head_dim) if self.scale_attn_weights else 1.0
         return s / float(self.layer_idx + 1) if self.scale_attn_by_inverse_layer_idx else s
 
+    def _p_attn(self, dropoutRate):
+        """Rate of the always-on dropout over the attention probabilities (:107-109,157-159; quirk 1: no training flag)."""
+        return dropoutRate if dropoutRate is not None else self.config.attn_pdrop
+
+    def _p_resid(self, dropoutRate):
+        """Rate of the always-on dropout over the attention block's output (:274-275)."""
+        return dropoutRate if dropoutRate is not None else self.config.resid_pdrop
+
     def nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
                                  customCasualMask=None, dropoutRate=None, output_attentions=False):
         """Reference signature (:119-120); the weights only under output_attentions=True (else None)."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is not supported on the fused path")
-        _check_no_attn_dropout(dropoutRate if dropoutRate is not None else self.config.attn_pdrop)
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
+        p = self._p_attn(dropoutRate)
         if output_attentions:
-            return branch_attention_core(query, key, value, lp, self._scale(), return_weights=True)
-        return branch_attention_core(query, key, value, lp, self._scale()), None
+            return branch_attention_core(query, key, value, lp, self._scale(), return_weights=True, p_drop=p)
+        return branch_attention_core(query, key, value, lp, self._scale(), p_drop=p), None
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, use_cache=False, output_attentions=False, nonResidual=False,
@@ -493,7 +528,7 @@ class GPT2NonResidualAttention(nn.Module):
         if nonResidual or nonResdiaulPastOnly or promptPast is not None or encoder_hidden_states is not None or \
                 layer_past is not None or attention_mask is not None or head_mask is not None:
             raise NotImplementedError()      # the reference raises for `nonResidual` too (:265-266); prompt modes are out of scope
-        _check_no_attn_dropout(dropoutRate if dropoutRate is not None else self.config.attn_pdrop)
+        p_attn = self._p_attn(dropoutRate)
         B, T, _ = hidden_states.shape
         qkv = self.c_attn(hidden_states).view(B, T, 3, self.num_heads, self.head_dim)
         query, key, value = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]     # strided views, no copies
@@ -501,13 +536,13 @@ class GPT2NonResidualAttention(nn.Module):
         weights = None
         if nonResidualTextOnly:
             lp = textualPast if hasattr(textualPast, "ctx_len") else _legacy_layer_past(textualPast, customCasualMask, T, qkv.device)
-            attn_output = branch_attention_core(query, key, value, lp, self._scale(), return_weights=output_attentions)
+            attn_output = branch_attention_core(query, key, value, lp, self._scale(), return_weights=output_attentions, p_drop=p_attn)
             if output_attentions:
                 attn_output, weights = attn_output
         else:
-            attn_output, weights = causal_attention_core(query, key, value, self._scale(), return_weights=output_attentions)
+            attn_output, weights = causal_attention_core(query, key, value, self._scale(), return_weights=output_attentions, p_drop=p_attn)
         attn_output = self.c_proj(attn_output.permute(0, 2, 1, 3).reshape(B, T, self.embed_dim))
-        p = dropoutRate if dropoutRate is not None else self.config.resid_pdrop
+        p = self._p_resid(dropoutRate)
         if p:
             attn_output = F.dropout(attn_output, p)          # always-on like the reference (:274-275, quirk 1)
         outputs = (attn_output, present)
@@ -543,9 +578,13 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
-    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None):
+    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None, dropoutRate=None):
         """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
-        block's MLP output - of the projection with weight delta_from -, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel."""
+        block's MLP output - of the projection with weight delta_from -, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel.
+        -> (x2, m, bias of m's projection or None, present, weight of m's projection or None): the last two are None when a
+        dropout sits between that projection and the residual add (the LayerNorm backward's shortcuts then do not apply).
+        Dropouts as in the reference: attention probabilities (inside the attention kernels) and attention output always on
+        at dropoutRate or the config's rates, the MLP's nn.Dropout in training mode only."""
         at = self.attn
         B, T, _ = x.shape
         # out_for / delta_from / qkv_from name the projection on the other side of a tensor: producers then write the stacked
@@ -555,13 +594,22 @@ class NonResidualGPT2Block(nn.Module):
         else:
             x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias, out_for=at.c_attn.weight, delta_from=delta_from)
         qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
-        a, present = fused.packed_attention(qkv, lp, at._scale(), out_for=at.c_proj.weight, qkv_from=at.c_attn.weight)
+        a, present = fused.packed_attention(qkv, lp, at._scale(), out_for=at.c_proj.weight, qkv_from=at.c_attn.weight,
+                                            p_drop=at._p_attn(dropoutRate))
         # the two projections that feed a residual add leave their bias gradient to the LayerNorm backward that follows
-        a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
-        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight)
+        p_res = at._p_resid(dropoutRate)
+        if p_res:
+            a = F.dropout(fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype), p_res, True)
+            x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, out_for=self.mlp.c_fc.weight)
+        else:
+            a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
+            x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight)
         g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh", out_for=self.mlp.c_proj.weight)
+        if self.mlp.resid_pdrop and self.training:
+            delta = F.dropout(fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), self.mlp.resid_pdrop, True)
+            return x2, delta, None, present, None
         delta = fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype, bias_grad=False)
-        return x2, delta, self.mlp.c_proj.bias, present
+        return x2, delta, self.mlp.c_proj.bias, present, self.mlp.c_proj.weight
 
 
 class NonResidualGPT2Model(_LMBase):
@@ -604,11 +652,14 @@ class NonResidualGPT2LMHeadModel(_LMBase):
             fused.prepare_weights(self, dtype)
             with torch.autocast("cuda", enabled=False):
                 x, delta, delta_bias, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, None, []
+                p_emb = dropoutRate if dropoutRate is not None else self.config.embd_pdrop
+                if p_emb:                                           # always on (NonResidualDiscriminatorBase.py:231-232)
+                    x = F.dropout(x, p_emb, True)
                 delta_from = None
                 for i, block in enumerate(tr.h):
-                    x, delta, delta_bias, present = block.fused_forward(x, delta, delta_bias, dtype,
-                                                                        _layer_past(textualPast, i) if branch else None, delta_from)
-                    delta_from = block.mlp.c_proj.weight
+                    x, delta, delta_bias, present, delta_from = block.fused_forward(x, delta, delta_bias, dtype,
+                                                                                    _layer_past(textualPast, i) if branch else None, delta_from,
+                                                                                    dropoutRate)
                     presents.append(present)
                 _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias, delta_from=delta_from)
                 head = self.lm_head if returnLmLogits else self.valueHead

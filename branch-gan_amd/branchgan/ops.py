@@ -4,6 +4,7 @@ Everything here launches hand-written gfx950 kernels through ctypes on torch's c
 torch supplies device memory and autograd bookkeeping only; there is no CPU or eager fallback.
 """
 import ctypes
+import itertools
 import math
 
 import torch
@@ -212,7 +213,57 @@ def _ptr_array(tensors):
     return arr
 
 
-def _attn_shape(q, k_text, slots_k, scale, max_path, out):
+# Dropout on the attention probabilities (csrc/attn_dropout.h).  One (seed, step counter) pair per device, in device memory: the
+# kernels read it when they run, so a captured step draws fresh masks on every replay once dropout_advance() is part of it.
+# A `drop` descriptor is (p, call): call tells the attention calls of one step apart and is the same in forward and backward.
+_drop_states = {}
+_drop_calls = itertools.count(1)
+
+
+def dropout_state(device):
+    """int64 (2,) on `device`: [seed, step counter]; created from torch's initial seed (seed_dropout() replaces it)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = str(device)
+    st = _drop_states.get(key)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        _drop_states[key] = st
+    return st
+
+
+def seed_dropout(seed, device="cuda"):
+    """Restart the attention-dropout stream of `device` at (seed, step 0), in place (captured graphs keep reading it)."""
+    dropout_state(device).copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def dropout_advance(device="cuda"):
+    """step counter += 1 on the current stream (bg_dropout_advance): once per train step, inside the captured region.  The
+    call numbers restart with it: the n-th attention call of a step has number n whether the step runs eagerly or is being
+    captured (a captured step and an eager one on the same (seed, counter) then draw the same masks)."""
+    global _drop_calls
+    C.check(C.lib().bg_dropout_advance(C.ptr(dropout_state(device)), C.stream_ptr()), "bg_dropout_advance")
+    _drop_calls = itertools.count(1)
+
+
+def drop_descriptor(p):
+    """(p, fresh call number) for one attention call, or None when p is 0 / None."""
+    if not p:
+        return None
+    if not 0.0 < float(p) < 1.0:
+        raise ValueError(f"attention dropout rate {p} is not in [0, 1)")
+    return (float(p), next(_drop_calls) & 0xFFFFFFFF)
+
+
+def attn_dropout_mask(sh_like, device):
+    """The keep mask of an attention call (bg_attn_dropout_mask; tests): uint8 (B, H, NQ*K, S_text + max_path)."""
+    keep = torch.empty((sh_like.B, sh_like.H, sh_like.NQ * sh_like.K, sh_like.S_text + sh_like.max_path), dtype=torch.uint8, device=device)
+    C.check(C.lib().bg_attn_dropout_mask(ctypes.byref(sh_like), C.ptr(keep), C.stream_ptr()), "bg_attn_dropout_mask")
+    return keep
+
+
+def _attn_shape(q, k_text, slots_k, scale, max_path, out, drop=None):
     B, H, NQ, K, Dh = q.shape
     sh = C.AttnShape()
     sh.dtype = C.dtype_code(q)
@@ -225,6 +276,9 @@ def _attn_shape(q, k_text, slots_k, scale, max_path, out):
         sh.t_sb, sh.t_sh, sh.t_ss = k_text.stride()[:3]
     if slots_k:
         sh.s_sb, sh.s_sh, sh.s_sk = slots_k[0].stride()[:3]
+    if drop is not None:
+        sh.p_drop, sh.drop_call = drop
+        sh.drop_state = dropout_state(q.device).data_ptr()
     return sh
 
 
@@ -296,7 +350,7 @@ class _BranchAttention(torch.autograd.Function):
     gradient tensor (slicing them outside costs a zero-fill, a copy and an add per node, per layer, for k and for v)."""
 
     @staticmethod
-    def forward(ctx, q, k_text, v_text, ctx_len, path, path_len, max_path, scale, n_slots, own_k, own_v, *slots):
+    def forward(ctx, q, k_text, v_text, ctx_len, path, path_len, max_path, scale, n_slots, own_k, own_v, drop, *slots):
         slots_k, slots_v = list(slots[:n_slots]), list(slots[n_slots:])
         C.require_cuda(q, k_text, v_text, ctx_len, *slots)
         q = _unit_last(q)
@@ -320,18 +374,18 @@ class _BranchAttention(torch.autograd.Function):
         # (B, NQ, K, H, Dh) in memory: the projection that follows reads it as (B, NQ*K, H*Dh) with no permute copy
         out = torch.empty((B, NQ, K, H, Dh), dtype=q.dtype, device=q.device).permute(0, 3, 1, 2, 4)
         lse = torch.empty((B, H, NQ, K), dtype=torch.float32, device=q.device)
-        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
+        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out, drop)
         attn_fwd_launch(sh, q, k_text, v_text, slots_k, slots_v, ctx_len, path, path_len, out, lse)
         has_own = own_k is not None
         ctx.save_for_backward(q, k_text, v_text, ctx_len, path, path_len, out, lse, *slots[:n_slots], *slots[n_slots:],
                               *((own_k, own_v) if has_own else ()))
-        ctx.meta = (max_path, scale, n_slots, has_own)
+        ctx.meta = (max_path, scale, n_slots, has_own, drop)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
-        max_path, scale, n_slots, has_own = ctx.meta
+        max_path, scale, n_slots, has_own, drop = ctx.meta
         q, k_text, v_text, ctx_len, path, path_len, out, lse = ctx.saved_tensors[:8]
         anc_k = list(ctx.saved_tensors[8:8 + n_slots])
         anc_v = list(ctx.saved_tensors[8 + n_slots:8 + 2 * n_slots])
@@ -356,18 +410,19 @@ class _BranchAttention(torch.autograd.Function):
         dq = torch.empty((B, H, NQ, K, Dh), dtype=q.dtype, device=q.device)
         dk_text, dv_text = like(k_text), like(k_text)
         delta = torch.empty_like(lse)
-        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out)
+        sh = _attn_shape(q, k_text, slots_k, scale, max_path, out, drop)
         sh.dq_sb, sh.dq_sh, sh.dq_sn, sh.dq_sk = dq.stride()[:4]
         attn_bwd_launch(sh, q, k_text, v_text, slots_k, slots_v, ctx_len, path, path_len, out, lse, dout, dq, dk_text, dv_text, None, None,
                         dks, dvs, delta)
-        return (dq, dk_text, dv_text, None, None, None, None, None, None, d_own_k, d_own_v, *d_anc_k, *d_anc_v)
+        return (dq, dk_text, dv_text, None, None, None, None, None, None, d_own_k, d_own_v, None, *d_anc_k, *d_anc_v)
 
 
-def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=None, scale=None, own_k=None, own_v=None):
+def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=None, scale=None, own_k=None, own_v=None, drop=None):
     """q (B,H,NQ,K,Dh) [or (B,H,K,Dh) = one node]; k_text/v_text (B,H,S,Dh); ctx_len int32 (K,) device;
     slots_k/v: lists of (B,H,K,Dh); own_k/own_v (optional, (B,H,NQ,K,Dh)): the query nodes' own keys / values, which become
     the slots after slots_k (slot len(slots_k) + n = node n); paths: per query node, the slot indices it may see (ancestors
-    + itself).  Returns (out like q [a (B,NQ,K,H,Dh)-contiguous view], lse fp32)."""
+    + itself); drop: None or drop_descriptor(p) - dropout on the attention probabilities.
+    Returns (out like q [a (B,NQ,K,H,Dh)-contiguous view], lse fp32)."""
     squeeze = q.dim() == 4
     if squeeze:
         q = q.unsqueeze(2)
@@ -399,11 +454,11 @@ def branch_attention(q, k_text, v_text, ctx_len, slots_k=(), slots_v=(), paths=N
         slots_k, slots_v = [t.contiguous() for t in slots_k], [t.contiguous() for t in slots_v]
         own_k, own_v = own_k.contiguous(), own_v.contiguous()
     out, lse = _BranchAttention.apply(q, k_text, v_text, ctx_len.contiguous(), path, path_len, max_path, float(scale),
-                                      len(slots_k), own_k, own_v, *slots_k, *slots_v)
+                                      len(slots_k), own_k, own_v, drop, *slots_k, *slots_v)
     return (out.squeeze(2), lse.squeeze(2)) if squeeze else (out, lse)
 
 
-def branch_attention_weights(q, k_text, ctx_len, slots_k, paths, scale, lse, own_k=None):
+def branch_attention_weights(q, k_text, ctx_len, slots_k, paths, scale, lse, own_k=None, drop=None):
     """The softmax weights of a branch_attention call, on request (bg_branch_attn_weights; no gradient).  Arguments as
     branch_attention; lse is the one it returned.  -> fp32 (B,H,NQ,K,W), W = S + (max_path - 1) * K + 1, the reference's
     column order [text | one K-column block per ancestor | self]."""
@@ -424,7 +479,7 @@ def branch_attention_weights(q, k_text, ctx_len, slots_k, paths, scale, lse, own
     path, path_len, max_path = path_tables(paths, q.device)
     W = k_text.shape[2] + (max(max_path - 1, 0) * K + 1 if max_path else 0)
     weights = torch.empty((B, H, NQ, K, max(W, 1)), dtype=torch.float32, device=q.device)
-    sh = _attn_shape(q, k_text, slots, scale, max_path, q)
+    sh = _attn_shape(q, k_text, slots, scale, max_path, q, drop)     # drop: the forward's descriptor -> the weights after dropout
     lse = lse.detach().contiguous().float()
     C.check(C.lib().bg_branch_attn_weights(ctypes.byref(sh), C.ptr(q), C.ptr(k_text), _ptr_array(slots), C.ptr(ctx_len.contiguous()),
                                            C.ptr(path), C.ptr(path_len), C.ptr(lse), C.ptr(weights), weights.shape[-1], C.stream_ptr()),
@@ -445,10 +500,10 @@ def causal_ctx_len(T_, S_, device):
     return ctx
 
 
-def causal_attention(q, k, v, scale=None):
+def causal_attention(q, k, v, scale=None, drop=None):
     """Root causal pass as the same kernel: query i sees keys j <= i + (S - T).  q (B,H,T,Dh), k/v (B,H,S,Dh)."""
     ctx = causal_ctx_len(q.shape[2], k.shape[2], q.device)
-    out, lse = branch_attention(q, k, v, ctx, (), (), paths=[[]], scale=scale)
+    out, lse = branch_attention(q, k, v, ctx, (), (), paths=[[]], scale=scale, drop=drop)
     return out, lse
 
 

@@ -17,6 +17,7 @@ import torch
 
 from . import fused, ops
 from . import sampling as SamplingStrategies
+from . import models
 from .models import BranchPast, DiscriminatorOutput
 from .sampling import SamplingTechniques
 
@@ -358,7 +359,7 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
     # logits with autograd, so the backward is one pass over N*K tokens instead of one per node.  Same mathematics as the
     # reference's per-node graph (MultiStepPrediction.py:296-327); dropout would draw different masks, so it keeps the old way.
     track = torch.is_grad_enabled() and logits.requires_grad
-    deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules)
+    deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules) and not models.dropout_active(generator)
     forwarded, pending = [], []
     rules = sampleRules[1:]
     for r_i, rule in enumerate(rules):

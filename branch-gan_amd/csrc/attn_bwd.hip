@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) 
 }
 
 template <typename T> int launch_bwd_split(const AttnArgs& a, hipStream_t st);      // attn_bwd_split.hip: 0 no, 1 slots left, 2 all
+bool attn_bwd_covers_dropout(const bg_attn_shape& sh);                                // attn_bwd_split.hip
 
 template <typename T>
 static void launch_slots(const AttnArgs& a, hipStream_t st) {
@@ -418,6 +419,9 @@ extern "C" int bg_branch_attn_bwd(const bg_attn_shape* shape, const void* q, con
     if (dv_text_in) if (int e = check_aligned16(dv_text_in, who, "dv_text_in")) return e;
   }
   BG_REQUIRE(shape->max_path == 0 || (path && path_len), "%s: null path/path_len", who);
+  BG_REQUIRE(shape->p_drop == 0.f || (attn_bwd_covers_dropout(*shape) && shape->NQ < (1 << 20)),
+             "%s: attention dropout needs the one-launch backward (Dh <= 128, a (batch, head) slice within 2^31 elements, "
+             "NQ*K <= 131072 rows, NQ < 2^20)", who);
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.sh = *shape;

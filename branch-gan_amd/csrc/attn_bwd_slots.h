@@ -2,6 +2,7 @@
 // one-launch backward (attn_bwd_split.hip).
 #pragma once
 #include "attn_common.h"
+#include "attn_dropout.h"
 
 namespace bg {
 
@@ -52,7 +53,9 @@ __device__ __forceinline__ void slot_store(T* p, const float (&v)[N]) {
 
 // OWN_DELTA: delta = rowsum(dO o O) is worked out here from the member's O row instead of being read from a.delta - the
 // form the one-launch backward uses, where no earlier kernel has written a.delta.
-template <typename T, int DH, bool OWN_DELTA>
+// DROP: attention dropout (attn_dropout.h); a member is listed with its path position (n | p << 20), the key column of this
+// slot in the node's row being S_text + p.
+template <typename T, int DH, bool OWN_DELTA, bool DROP = false>
 __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members /* [256] */, int* s_count /* [ATT_WAVES] */, int slot, int bh) {
   constexpr int LPR = 8, PER = DH / LPR;
   constexpr int U = (PER <= 8 ? 4 : (PER <= 16 ? 2 : 1)) / (OWN_DELTA && PER <= 16 ? 2 : 1);   // U: members whose loads are in flight together
@@ -67,6 +70,9 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
   for (int sidx = 0; sidx < sh.n_slots; ++sidx)
     if (sidx == slot) { kslot = (const T*)a.k_slots[sidx]; vslot = (const T*)a.v_slots[sidx]; dkslot = (T*)a.dk_slots[sidx]; dvslot = (T*)a.dv_slots[sidx]; }
 
+  [[maybe_unused]] DropKeys drop;
+  if constexpr (DROP) drop = drop_keys(a, bh);
+
   for (int k0 = 0; k0 < sh.K; k0 += 256 / LPR) {
     const int kq = k0 + tid / LPR;
     const bool valid = kq < sh.K;
@@ -80,9 +86,14 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
     for (int n0 = 0; n0 < sh.NQ; n0 += 256) {
       const int nt = n0 + tid;
       bool member = false;
+      [[maybe_unused]] int member_p = 0;
       if (nt < sh.NQ) {                                 // every entry of the row is loaded at once (no wait on path_len first)
         const int plen = sh.max_path ? a.path_len[nt] : 0;
-        for (int p = 0; p < sh.max_path; ++p) member |= (a.path[nt * sh.max_path + p] == slot) & (p < plen);
+        for (int p = 0; p < sh.max_path; ++p) {
+          const bool hit = (a.path[nt * sh.max_path + p] == slot) & (p < plen);
+          member |= hit;
+          if constexpr (DROP) member_p = hit ? p : member_p;
+        }
       }
       const unsigned long long bal = __ballot(member);
       __syncthreads();  // the previous chunk's list is no longer read
@@ -91,15 +102,21 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
       int base = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < ATT_WAVES; ++w) { const int c = s_count[w]; base += (w < wave) ? c : 0; total += c; }
-      if (member) s_members[base + __popcll(bal & ((1ull << lane) - 1ull))] = nt;
+      if (member) s_members[base + __popcll(bal & ((1ull << lane) - 1ull))] = DROP ? (nt | (member_p << 20)) : nt;
       __syncthreads();
 
       for (int m0 = 0; m0 < total; m0 += U) {
         float qq[U][PER], dd[U][PER], ls[U], de[U];
+        [[maybe_unused]] float mk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool on = valid && (m0 + u < total);
-          const int n = s_members[min(m0 + u, total - 1)];
+          int n = s_members[min(m0 + u, total - 1)];
+          if constexpr (DROP) {
+            const int p = n >> 20;
+            n &= (1 << 20) - 1;
+            mk[u] = drop_keep(drop, drop_row_key(drop, (uint32_t)(n * sh.K + kq)), (uint32_t)(sh.S_text + p)) ? drop.inv_keep : 0.f;
+          }
           const int64_t qoff = (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh + (int64_t)n * sh.q_sn + (int64_t)(valid ? kq : 0) * sh.q_sk + sub * PER;
           const int64_t ooff = (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n * sh.o_sn + (int64_t)(valid ? kq : 0) * sh.o_sk + sub * PER;
           const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + (valid ? kq : 0);
@@ -130,8 +147,10 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
           }
 #pragma unroll
           for (int o = 1; o < LPR; o <<= 1) { sdot += __shfl_xor(sdot, o); pdot += __shfl_xor(pdot, o); }
-          const float pw = valid ? __expf(sdot * sh.scale - ls[u]) : 0.f;
+          float pw = valid ? __expf(sdot * sh.scale - ls[u]) : 0.f;
+          if constexpr (DROP) pdot *= mk[u];
           const float ds = valid ? pw * (pdot - de[u]) * sh.scale : 0.f;
+          if constexpr (DROP) pw *= mk[u];
 #pragma unroll
           for (int j = 0; j < PER; ++j) {
             dk[j] = fmaf(ds, qq[u][j], dk[j]);

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "attn_bwd_slots.h"
+#include "attn_dropout.h"
 
 namespace bg {
 
@@ -39,7 +40,7 @@ __device__ unsigned long long g_attn_trace[2][BG_TRACE_WAVES][16];
 template <typename T, int DH, int DPASS> struct BwdSplitLds {
   using L = Lds<T, DH>;
   static constexpr size_t TILE_BYTES = ((size_t)L::ROW_ELEMS * sizeof(T) + 15) / 16 * 16;
-  static constexpr size_t STAT_BYTES = 3 * ATT_TILE * 4;                               // lse, delta, ctx of a gathered query tile
+  static constexpr size_t STAT_BYTES = 4 * ATT_TILE * 4;                               // lse, delta, ctx (and dropout row key) of a gathered query tile
   static constexpr size_t WAVE_BYTES = 2 * TILE_BYTES + STAT_BYTES;
   static constexpr size_t MERGE_BYTES = (size_t)ATT_WAVES * DPASS * ATT_TILE * sizeof(float);
   static constexpr size_t STAGE_BYTES = (ATT_WAVES * WAVE_BYTES > MERGE_BYTES ? ATT_WAVES * WAVE_BYTES : MERGE_BYTES);
@@ -89,7 +90,9 @@ __device__ __forceinline__ void store_vec(T* p, const float (&acc)[PER], const T
 
 // ---------------------------------------------------------------------------------------------------
 // dQ (and delta): one 32-query tile per workgroup, the key tiles dealt round-robin to the four waves.
-template <typename T, int DH>
+// DROP (all three tile functions): dropout on the attention probabilities (attn_dropout.h).  With M the keep mask scaled by
+// 1 / (1 - p):  O = (P o M) V, so dV = (P o M)^T dO, dP = (dO V^T) o M, dS = P o (dP - delta) with delta = rowsum(dO o O) as before.
+template <typename T, int DH, bool DROP>
 __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int tile_x, int bh) {
   using SL = BwdSplitLds<T, DH, DH>;
   constexpr int NDT = DH / 32;
@@ -113,6 +116,12 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
   const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
   const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
   const int64_t stat = ((int64_t)bh * sh.NQ + n) * sh.K + kq;
+  [[maybe_unused]] DropKeys drop;
+  [[maybe_unused]] uint32_t row_key = 0;
+  if constexpr (DROP) {
+    drop = drop_keys(a, bh);
+    row_key = drop_row_key(drop, (uint32_t)rq);
+  }
 
   // Everything this wave needs first goes out in ONE round of loads: the context lengths, the workgroup's Q / dO / O tile
   // and - before the number of key tiles is known - key tile `wave` (dropped if the tile turns out to be beyond the context).
@@ -203,7 +212,9 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
     for (int r = 0; r < 16; ++r) {
       const int key = kb + tile_row(r, h);
       const float p = (key < ctx) ? __expf(s[r] * sh.scale - lse) : 0.f;
-      s[r] = p * (dp[r] - delta) * sh.scale;  // dS^T
+      float dpr = dp[r];
+      if constexpr (DROP) dpr = drop_keep(drop, row_key, (uint32_t)key) ? dpr * drop.inv_keep : 0.f;
+      s[r] = p * (dpr - delta) * sh.scale;  // dS^T
     }
     if (t == wave) BG_TRACE(0, 10);
     if constexpr (sizeof(T) == 4) mma_reduce_rows<T, DH, 0, NDT>(dq, s, k_row, lane);
@@ -222,7 +233,8 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
     for (int sidx = 0; sidx < sh.n_slots; ++sidx)
       if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
     const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
-    const float dpv = pair_dot<T, DH>(do_row, vr, h, act);
+    float dpv = pair_dot<T, DH>(do_row, vr, h, act);
+    if constexpr (DROP) dpv = drop_keep(drop, row_key, (uint32_t)(sh.S_text + p)) ? dpv * drop.inv_keep : 0.f;
     if (act) {
       const float pw = __expf(sc - lse);
       axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
@@ -261,7 +273,7 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
 // waves.  [DT0, DT1) is the slice of d (in 32s) this launch accumulates: all of it up to DH = 128, two launches at 256.
 // OWN_DELTA: delta = rowsum(dO o O) of a gathered query tile is worked out here, from its O rows, instead of being read from
 // a.delta (the one-launch backward, where the dQ workgroups that write a.delta run beside this one, not before it).
-template <typename T, int DH, int DT0, int DT1, bool OWN_DELTA>
+template <typename T, int DH, int DT0, int DT1, bool OWN_DELTA, bool DROP = false>
 __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int tile_x, int bh) {
   constexpr int DPASS = (DT1 - DT0) * 32;
   constexpr bool PREFETCH = DH >= 128;
@@ -276,6 +288,10 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
   float* lse_s = (float*)(smem + wave * SL::WAVE_BYTES + 2 * SL::TILE_BYTES);
   float* delta_s = lse_s + ATT_TILE;
   int* ctx_s = (int*)(delta_s + ATT_TILE);
+  [[maybe_unused]] uint32_t* rkey_s = (uint32_t*)(ctx_s + ATT_TILE);
+  [[maybe_unused]] DropKeys drop;
+  [[maybe_unused]] uint32_t g_rkey = 0;
+  if constexpr (DROP) drop = drop_keys(a, bh);
   int* reach_s = (int*)(smem + SL::BYTES);               // one int per query tile, behind the staging / merge area
 
   const int b = bh / sh.H, hh = bh % sh.H;
@@ -320,6 +336,7 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
     g_ctx = qv ? min(a.ctx_len[kk], sh.S_text) : 0;      // 0 for rows past the end: masks everything
     g_lse = qv ? a.lse[stat] : 0.f;
     if constexpr (!OWN_DELTA) g_delta = qv ? a.delta[stat] : 0.f;
+    if constexpr (DROP) g_rkey = drop_row_key(drop, (uint32_t)rq);
   };
 
   // the gathered tile goes to this wave's staging area (row layout), with its rows' lse / ctx and delta
@@ -351,6 +368,7 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       lse_s[lane] = g_lse;
       if constexpr (!OWN_DELTA) delta_s[lane] = g_delta;
       ctx_s[lane] = g_ctx;
+      if constexpr (DROP) rkey_s[lane] = g_rkey;
     }
   };
 
@@ -464,12 +482,16 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       const f32x4 lse4 = *(const f32x4*)(lse_s + 8 * g + 4 * h);
       const f32x4 del4 = *(const f32x4*)(delta_s + 8 * g + 4 * h);
       const i32x4 ctx4 = *(const i32x4*)(ctx_s + 8 * g + 4 * h);
+      [[maybe_unused]] i32x4 rk4;
+      if constexpr (DROP) rk4 = *(const i32x4*)(rkey_s + 8 * g + 4 * h);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * g + j;
         const float p = (key < ctx4[j]) ? __expf(s[r] * sh.scale - lse4[j]) : 0.f;
-        dp[r] = p * (dp[r] - del4[j]) * sh.scale;  // dS
-        s[r] = p;                                  // P
+        float mk = 1.f;
+        if constexpr (DROP) mk = drop_keep(drop, (uint32_t)rk4[j], (uint32_t)key) ? drop.inv_keep : 0.f;
+        dp[r] = p * (dp[r] * mk - del4[j]) * sh.scale;  // dS
+        s[r] = p * mk;                                  // P o M
       }
     }
     if (my_tiles == 1) BG_TRACE(1, 10);
@@ -523,7 +545,7 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void branch_attn_bwd_dq_split_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const BlockXY blk = xcd_block();
-  bwd_dq_tile<T, DH>(a, smem, blk.x, blk.y);
+  bwd_dq_tile<T, DH, false>(a, smem, blk.x, blk.y);
 }
 
 template <typename T, int DH, int DT0, int DT1>
@@ -537,7 +559,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
 // block numbers that are congruent mod 8, i.e. one XCD and one L2 (blocks are dealt round-robin over the 8 XCDs), and
 // within a head the order is heaviest first - key tiles from 0 (under a causal mask tile 0 is reached by every query
 // tile), query tiles from the last one down, then the slot rows.
-template <typename T, int DH>
+template <typename T, int DH, bool DROP = false>
 __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_bwd_one_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bg_attn_shape& sh = a.sh;
@@ -553,9 +575,9 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     bh = id / per_head;
     item = id % per_head;
   }
-  if (item < nk) bwd_dkv_tile<T, DH, 0, DH / 32, true>(a, smem, item, bh);
-  else if (item < nk + nq) bwd_dq_tile<T, DH>(a, smem, nq - 1 - (item - nk), bh);
-  else bwd_slot_rows<T, DH, true>(a, (int*)smem, (int*)smem + 256, item - nk - nq, bh);
+  if (item < nk) bwd_dkv_tile<T, DH, 0, DH / 32, true, DROP>(a, smem, item, bh);
+  else if (item < nk + nq) bwd_dq_tile<T, DH, DROP>(a, smem, nq - 1 - (item - nk), bh);
+  else bwd_slot_rows<T, DH, true, DROP>(a, (int*)smem, (int*)smem + 256, item - nk - nq, bh);
 }
 
 template <typename T, int DH, int DT0, int DT1>
@@ -578,9 +600,16 @@ static int launch_split(const AttnArgs& a, bool one, hipStream_t st) {
       size_t lds = lq > lk + reach ? lq : lk + reach;
       if (lds < (256 + ATT_WAVES) * sizeof(int)) lds = (256 + ATT_WAVES) * sizeof(int);
       const int64_t per_head = cdiv((int64_t)sh.S_text, ATT_TILE) + cdiv(R, ATT_TILE) + sh.n_slots;
+      const dim3 grid((unsigned)(per_head * sh.B * sh.H));
+      if (sh.p_drop > 0.f) {
+        auto kernel = branch_attn_bwd_one_kernel<T, DH, true>;
+        set_lds_limit(kernel, lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+        return 2;
+      }
       auto kernel = branch_attn_bwd_one_kernel<T, DH>;
       set_lds_limit(kernel, lds);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(per_head * sh.B * sh.H)), dim3(256), lds, st, a);
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
       return 2;
     }
   }
@@ -616,20 +645,26 @@ template <typename T>
 int launch_bwd_split(const AttnArgs& a, hipStream_t st) {
   static const bool enabled = [] { const char* e = getenv("BRANCHGAN_ATTN_BWD_SPLIT"); return !(e && e[0] == '0'); }();
   static const bool one = [] { const char* e = getenv("BRANCHGAN_ATTN_BWD_ONE"); return !(e && e[0] == '0'); }();
-  if (!enabled) return 0;
   const bg_attn_shape& sh = a.sh;
+  const bool drop = sh.p_drop > 0.f;                     // dropout lives in the one-launch form only (attn_bwd_covers_dropout)
+  if (!enabled && !drop) return 0;
   if (sizeof(T) == 4 && sh.Dh == 256) return 0;
   if (!slice_fits_32(sh)) return 0;
   // reach_s lives behind the staging area: one int per query tile
   if ((size_t)cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * 4 > 16 * 1024) return 0;
   switch (sh.Dh) {
-    case 32: return launch_split<T, 32>(a, one, st);
-    case 64: return launch_split<T, 64>(a, one, st);
-    case 128: return launch_split<T, 128>(a, one, st);
+    case 32: return launch_split<T, 32>(a, one || drop, st);
+    case 64: return launch_split<T, 64>(a, one || drop, st);
+    case 128: return launch_split<T, 128>(a, one || drop, st);
     default:
       if constexpr (sizeof(T) == 2) return launch_split<T, 256>(a, one, st);
       return 0;
   }
+}
+
+// The shapes whose backward can apply dropout: the ones the one-launch form takes.
+bool attn_bwd_covers_dropout(const bg_attn_shape& sh) {
+  return sh.Dh <= 128 && slice_fits_32(sh) && (size_t)cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * 4 <= 16 * 1024;
 }
 
 #ifdef BG_ATTN_TRACE

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "attn_common.h"
+#include "attn_dropout.h"
 
 namespace bg {
 
@@ -175,7 +176,9 @@ template <typename T, int DH> struct SplitLds {
 // Layout of a.part per (bh, query tile, split): [DH][32] outputs (feature-major, query on the lane) then [2][32] = max, sum.
 template <int DH> constexpr size_t fwd_part_floats() { return (size_t)(DH + 2) * ATT_TILE; }
 
-template <typename T, int DH, bool KVSPLIT = false>
+// DROP: dropout on the attention probabilities (attn_dropout.h) - the sum l runs over the undropped weights, the products with V
+// over the kept ones, the output is scaled by 1 / (1 - p) at the end.
+template <typename T, int DH, bool KVSPLIT = false, bool DROP = false>
 __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_fwd_split_kernel(AttnArgs a) {
   using SL = SplitLds<T, DH>;
   constexpr int NDT = DH / 32;
@@ -198,6 +201,12 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   const int n = valid ? rq / sh.K : 0, kq = valid ? rq % sh.K : 0;
   const T* kt = (const T*)a.k_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
   const T* vt = (const T*)a.v_text + (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+  [[maybe_unused]] DropKeys drop;
+  [[maybe_unused]] uint32_t row_key = 0;
+  if constexpr (DROP) {
+    drop = drop_keys(a, bh);
+    row_key = drop_row_key(drop, (uint32_t)rq);
+  }
   // ONE round of loads: context length, path, the Q tile and - before the number of key tiles is known - key tile `wave`
   int ctx = valid ? a.ctx_len[kq] : 0;
   const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
@@ -262,6 +271,10 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     psum += __shfl_xor(psum, 32);
     l = l * alpha + psum;
     m = m_new;
+    if constexpr (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = drop_keep(drop, row_key, (uint32_t)(kb + tile_row(r, h))) ? s[r] : 0.f;
+    }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -291,7 +304,9 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
       for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-      axpy_rowvec<T, DH>(o, pw, vr, h, true);
+      bool kept = true;
+      if constexpr (DROP) kept = drop_keep(drop, row_key, (uint32_t)(sh.S_text + p));
+      if (kept) axpy_rowvec<T, DH>(o, pw, vr, h, true);
     }
   }
 
@@ -344,7 +359,8 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
         }
         return;
       }
-      const float inv = (lstar > 0.f) ? 1.f / lstar : 0.f;
+      float inv = (lstar > 0.f) ? 1.f / lstar : 0.f;
+      if constexpr (DROP) inv *= drop.inv_keep;
       T* o_row = (T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh + (int64_t)n2 * sh.o_sn + (int64_t)k2 * sh.o_sk + grp * PER;
       float acc[PER];
 #pragma unroll
@@ -424,7 +440,7 @@ int attn_fwd_kv_splits(const bg_attn_shape& sh) {
   const bool fits = sh.Dh <= 128 || (sh.Dh == 256 && sh.dtype == BG_BF16);
   const int64_t wgs = cdiv((int64_t)sh.NQ * sh.K, ATT_TILE) * sh.B * sh.H;
   const int nk = (int)cdiv((int64_t)sh.S_text, ATT_TILE);
-  if (!fits || forced == 0 || nk < 2 * ATT_WAVES) return 1;
+  if (!fits || forced == 0 || nk < 2 * ATT_WAVES || sh.p_drop > 0.f) return 1;
   int ns = forced > 0 ? forced : (int)cdiv(256, wgs);
   if (forced < 0 && (wgs > 128 || nk < 3 * ATT_WAVES)) return 1;
   ns = ns < nk / ATT_WAVES ? ns : nk / ATT_WAVES;          // every split has a tile for each of its four waves
@@ -454,6 +470,11 @@ int validate_attn_shape(const bg_attn_shape* s, const char* who) {
   const int64_t al = (s->dtype == BG_F32) ? 4 : 8;  // elements per 16 bytes
   const int64_t st[] = {s->q_sb, s->q_sh, s->q_sn, s->q_sk, s->o_sb, s->o_sh, s->o_sn, s->o_sk, s->t_sb, s->t_sh, s->t_ss, s->s_sb, s->s_sh, s->s_sk};
   for (int64_t v : st) BG_REQUIRE(v >= 0 && v % al == 0, "%s: stride %lld is not a multiple of %lld elements (16 bytes)", who, (long long)v, (long long)al);
+  BG_REQUIRE(s->p_drop >= 0.f && s->p_drop < 1.f, "%s: p_drop=%g is not in [0, 1)", who, (double)s->p_drop);
+  if (s->p_drop > 0.f) {
+    BG_REQUIRE(s->drop_state, "%s: p_drop > 0 needs drop_state (device: seed, step counter)", who);
+    BG_REQUIRE(s->Dh <= 128, "%s: attention dropout is built for Dh <= 128 (Dh=%d)", who, s->Dh);
+  }
   return BG_OK;
 }
 
@@ -465,6 +486,14 @@ int check_aligned16(const void* p, const char* who, const char* name) {
 template <typename T, int DH>
 static void launch_fwd_split(const AttnArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = SplitLds<T, DH>::BYTES;
+  if (a.sh.p_drop > 0.f) {                               // validated by the entry point: Dh <= 128, no key-range split
+    if constexpr (DH <= 128) {
+      auto kernel = branch_attn_fwd_split_kernel<T, DH, false, true>;
+      set_lds_limit(kernel, lds);
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+    }
+    return;
+  }
   if (a.kv_splits > 1) {
     auto kernel = branch_attn_fwd_split_kernel<T, DH, true>;
     set_lds_limit(kernel, lds);
@@ -490,7 +519,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
   // Dh 256: the four waves' K / V tiles + the Q tile fit the 160 KB of LDS in bf16 only (152 KB; fp32 would need 280 KB)
   static const bool split_256 = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_SPLIT_256"); return !(e && e[0] == '0'); }();
   const bool fits = sh.Dh <= 128 || (sh.Dh == 256 && sizeof(T) == 2 && split_256);
-  const bool split = fits && (all_split || a.kv_splits > 1 || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
+  const bool split = fits && (all_split || a.kv_splits > 1 || sh.p_drop > 0.f || (R <= 128 && cdiv(R, ATT_WAVES * ATT_TILE) * sh.B * sh.H <= 512));
   if (split) {
     switch (sh.Dh) {
       case 32: launch_fwd_split<T, 32>(a, grid_split, st); break;
@@ -549,7 +578,7 @@ extern "C" int bg_branch_attn_fwd_ws(const bg_attn_shape* shape, const void* q, 
   a.q = q; a.k_text = k_text; a.v_text = v_text; a.ctx_len = ctx_len; a.path = path; a.path_len = path_len;
   a.out = out; a.lse = lse;
   a.kv_splits = 1;
-  if (workspace) {                                       // enough workspace: the key range of a query tile may be split
+  if (workspace && shape->p_drop == 0.f) {               // enough workspace: the key range of a query tile may be split
     const size_t need = attn_fwd_workspace_bytes(*shape);
     if (need > 0 && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0) {
       a.kv_splits = attn_fwd_kv_splits(*shape);

@@ -6,6 +6,7 @@
 // [text 0..S-1 | ancestor depth 1 (K columns) | ... | self].  A diagnostic path: one workgroup per query row, plain dot
 // products, coalesced stores of the row; no attempt at MFMA.
 #include "attn_common.h"
+#include "attn_dropout.h"
 
 namespace bg {
 
@@ -25,6 +26,15 @@ __global__ __launch_bounds__(256) void branch_attn_weights_kernel(AttnArgs a, fl
   if (tid < sh.Dh) qs[tid] = to_f32(q[tid]);
   __syncthreads();
   const float lse = a.lse[(((int64_t)b * sh.H + h) * sh.NQ + n) * sh.K + k];
+  // with dropout the reference hands out the weights AFTER the dropout (kept ones scaled by 1 / (1 - p)): the same mask here
+  const bool dropping = sh.p_drop > 0.f;
+  DropKeys drop = {0u, 0u, 0u, 1.f};
+  uint32_t row_key = 0;
+  if (dropping) {
+    drop = drop_keys(a, b * sh.H + h);
+    row_key = drop_row_key(drop, (uint32_t)(n * sh.K + k));
+  }
+  auto mask_of = [&](int column) -> float { return !dropping ? 1.f : (drop_keep(drop, row_key, (uint32_t)column) ? drop.inv_keep : 0.f); };
   float* w = weights + (int64_t)blockIdx.x * W;
   auto weight_of = [&](const T* key) -> float {
     float dot = 0.f;
@@ -33,7 +43,7 @@ __global__ __launch_bounds__(256) void branch_attn_weights_kernel(AttnArgs a, fl
   };
   const int ctx = min(a.ctx_len[k], sh.S_text);
   const T* kt = (const T*)a.k_text + b * sh.t_sb + h * sh.t_sh;
-  for (int c = tid; c < sh.S_text; c += 256) w[c] = c < ctx ? weight_of(kt + (int64_t)c * sh.t_ss) : 0.f;
+  for (int c = tid; c < sh.S_text; c += 256) w[c] = c < ctx ? weight_of(kt + (int64_t)c * sh.t_ss) * mask_of(c) : 0.f;
   for (int c = sh.S_text + tid; c < W; c += 256) w[c] = 0.f;
   __syncthreads();
   // the node's own path: ancestors on the diagonal of their K-column block, the last entry (itself) in the last column
@@ -42,7 +52,7 @@ __global__ __launch_bounds__(256) void branch_attn_weights_kernel(AttnArgs a, fl
     const int slot = a.path[n * sh.max_path + tid];
     const T* key = (const T*)a.k_slots[slot] + b * sh.s_sb + h * sh.s_sh + k * sh.s_sk;
     const int col = tid == plen - 1 ? W - 1 : sh.S_text + tid * sh.K + k;
-    w[col] = weight_of(key);
+    w[col] = weight_of(key) * mask_of(sh.S_text + tid);
   }
 }
 

@@ -167,6 +167,17 @@ typedef struct {
   int64_t s_sb, s_sh, s_sk;           /* every slot tensor (and its gradient) */
   int64_t dq_sb, dq_sh, dq_sn, dq_sk; /* backward only: strides of dq; all zero = the o_* strides.  Lets dq, dk, dv land in
                                          one packed dqkv buffer (the layout q, k, v were sliced from) with no gather */
+  /* Dropout on the attention probabilities (GPT-2: NonResidualAttention.py:107-109,157-159, always on; NeoX:
+   * NeoXNonResidualAttention.py:224,287): the weights are normalised over all visible keys, then each is kept with probability
+   * 1 - p_drop and scaled by 1 / (1 - p_drop); lse is that of the undropped softmax.  p_drop = 0 (the zero-initialised
+   * struct): no dropout, the fields below are ignored.  The mask is never stored: it is a counter-based function of
+   * (drop_state[0] = seed, drop_state[1] = step counter, drop_call, batch*head, query row n*K + k, key column), regenerated by
+   * the backward call that passes the same p_drop / drop_call / drop_state contents (bg_attn_dropout_mask writes it out).
+   * drop_state is DEVICE memory read when the kernel runs: advance the counter (bg_dropout_advance) between the replays of
+   * a captured graph to draw fresh masks; drop_call tells the attention calls of one step apart.  Dh <= 128 only. */
+  float p_drop;
+  uint32_t drop_call;
+  const uint64_t* drop_state;
 } bg_attn_shape;
 
 int bg_branch_attn_fwd(const bg_attn_shape* shape,
@@ -211,6 +222,15 @@ int bg_branch_attn_bwd(const bg_attn_shape* shape,
 int bg_branch_attn_weights(const bg_attn_shape* shape, const void* q, const void* k_text, const void* const* k_slots /* host array */,
                            const int32_t* ctx_len, const int32_t* path, const int32_t* path_len, const float* lse,
                            float* weights, int W, void* stream);
+
+/* The keep mask of an attention call with shape->p_drop > 0, written out (tests, debugging; the attention kernels never store
+ * it): keep uint8 [b][h][n*K + k][S_text + max_path], 1 = kept; column S_text + p belongs to entry p of the node's path.
+ * Every position gets its decision, visible or not.  No counterpart in the reference (torch draws its mask from the global
+ * generator inside F.dropout); the oracle applies this mask to its own softmax weights to check the kernels. */
+int bg_attn_dropout_mask(const bg_attn_shape* shape, uint8_t* keep, void* stream);
+
+/* drop_state[1] += 1 on the stream (one thread): the step counter of the dropout masks, see bg_attn_shape. */
+int bg_dropout_advance(uint64_t* drop_state, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NeoX prologue: split the fused QKV projection, move heads forward and apply partial rotary.

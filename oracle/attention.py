@@ -19,13 +19,22 @@ def default_branch_mask(q_len, k_len):
     return torch.cat((text, torch.ones(q_len, 1, dtype=torch.bool)), dim=1)[None, None]
 
 
+def _dropout(w, keep, p_drop):
+    """F.dropout(w, p) with the Bernoulli draw handed in: torch computes `w * keep / (1 - p)` (GPT-2 :107-109,157-159 always
+    on; NeoX :224,287 nn.Dropout).  keep None: the identity (p = 0)."""
+    if keep is None:
+        return w
+    return w * keep.to(w.dtype) * (1.0 / (1.0 - p_drop))
+
+
 def branch_attention(family, q, k_self, v_self, k_ctx, v_ctx, mask=None, layer_idx=0,
-                     scale_attn_weights=True, scale_by_inverse_layer_idx=False):
+                     scale_attn_weights=True, scale_by_inverse_layer_idx=False, keep=None, p_drop=0.0):
     """`_nonResidualTextAttention` (NeoX :183-232) / `nonResidualTextAttention` (GPT-2 :119-172).
 
     q, k_self, v_self (B,H,K,Dh); k_ctx, v_ctx (B,H,C,Dh); mask bool broadcastable to (B,1,K,C+1) whose
-    last column is the self column.  Returns (out (B,H,K,Dh), weights (B,H,K,C+1)).  Dropout is the
-    identity here (p = 0 in every parity run)."""
+    last column is the self column.  Returns (out (B,H,K,Dh), weights (B,H,K,C+1)).  Dropout over the
+    weights: the identity unless the draw is handed in (keep, bool like the weights, with its rate p_drop):
+    torch's generator cannot be matched, so parity tests give both sides the same draw."""
     dh = q.shape[-1]
     scores = torch.cat((q @ k_ctx.transpose(-1, -2), (q * k_self).sum(-1, keepdim=True)), dim=-1)
     if family == NEOX:
@@ -40,12 +49,12 @@ def branch_attention(family, q, k_self, v_self, k_ctx, v_ctx, mask=None, layer_i
     if mask is None:
         mask = default_branch_mask(q.shape[-2], k_ctx.shape[-2])
     scores = torch.where(mask, scores, torch.tensor(fill, dtype=scores.dtype))
-    w = torch.softmax(scores, dim=-1)
+    w = _dropout(torch.softmax(scores, dim=-1), keep, p_drop)
     out = w[..., :-1] @ v_ctx + w[..., -1:] * v_self
     return out, w
 
 
-def causal_attention(family, q, k, v, layer_idx=0, scale_attn_weights=True, scale_by_inverse_layer_idx=False):
+def causal_attention(family, q, k, v, layer_idx=0, scale_attn_weights=True, scale_by_inverse_layer_idx=False, keep=None, p_drop=0.0):
     """Root pass: NeoX `_attn` :234-290 with `_maskFunc` :292-301 (scores*m + (-1e9)(1-m)),
     GPT-2 `_attn` :78-117 (where(mask, scores, -1e4)).  q (B,H,T,Dh), k/v (B,H,S,Dh), T <= S."""
     t, s, dh = q.shape[-2], k.shape[-2], q.shape[-1]
@@ -64,7 +73,7 @@ def causal_attention(family, q, k, v, layer_idx=0, scale_attn_weights=True, scal
         if scale_by_inverse_layer_idx:
             scores = scores / float(layer_idx + 1)
         scores = torch.where(causal, scores, torch.tensor(-1e4))
-    w = torch.softmax(scores, dim=-1)
+    w = _dropout(torch.softmax(scores, dim=-1), keep, p_drop)
     return w @ v, w
 
 
