@@ -43,7 +43,7 @@ WORKLOADS = {
 WORKLOADS["tiny"] = dict(gen="gpt2-tiny", disc="gpt2-tiny", S=64, K=8, D=3, B=4, name="rehearsal only: 2-layer 128-wide GPT-2 pair")
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
-PMC_TOPN, PMC_TOPP = "r2_pmc_topn.json", "r2_pmc_topp.json"      # profiles/: rocprofv3 --pmc passes over benchmarks/sampling_mix.py
+PMC_TOPN, PMC_TOPP = "r3_pmc_topn.json", "r3_pmc_topp.json"      # profiles/: rocprofv3 --pmc passes over benchmarks/sampling_mix.py
 
 
 def zipf_ids(n, S, V, seed):

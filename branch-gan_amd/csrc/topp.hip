@@ -688,7 +688,7 @@ __global__ void topp_reset_kernel(int* todo) { todo[0] = 0; }
 // workspace and redone by the first form in a second launch of a few persistent workgroups: same results.
 #define TOPP_NOISE_EARLY 7                        // noise vectors requested before the candidate pass (registers)
 #define TOPP_REGION 768                           // list entries per wave (16 regions: 96 KB)
-// 96 KB of regions + 8 KB of histograms and lists: more static LDS than any part but gfx950 (160 KB per CU) offers.  The
+// 96 KB of regions + 48 KB of their noise + 8 KB of histograms and lists: more static LDS than any part but gfx950 (160 KB per CU) offers.  The
 // library is written for gfx950 only (csrc/Makefile); a build for another --offload-arch stops here with a message instead of
 // failing somewhere inside the linker.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
@@ -696,6 +696,7 @@ __global__ void topp_reset_kernel(int* todo) { todo[0] = 0; }
 #endif
 __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int* todo) {
   __shared__ u64 big[(TOPP_THREADS / 64) * TOPP_REGION];     // level 1: 256 exponents x 16 replicas of u64 sums; then the regions
+  __shared__ float noise_l[(TOPP_THREADS / 64) * TOPP_REGION]; // the noise of the regions' entries, position for position
   __shared__ double e_sum[256];
   __shared__ double h_sum[256];
   __shared__ unsigned h_cnt[256];
@@ -797,6 +798,9 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int
   u64* region = big + wave * TOPP_REGION;
   unsigned mine = 0;                                   // wave-uniform count
   const unsigned lowest = b1 << 23;                  // positive floats order like their bit patterns
+  // which of this thread's 52 elements were listed (bit 4 c + j): the key pass walks the same ballots again, so an entry's
+  // position in the region - and with it the thread that holds the entry's noise in its registers - needs no look-up
+  u64 listed = 0;
 #pragma unroll
   for (int c = 0; c < TOPP_NV; ++c) {
     const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
@@ -812,6 +816,7 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int
       if (bal == 0) continue;
       const unsigned pos = mine + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
       if (hit && pos < TOPP_REGION) region[pos] = ((u64)(uint32_t)(i0 + j) << 32) | u;
+      listed |= hit ? (1ull << (4 * c + j)) : 0ull;
       mine += (unsigned)__popcll(bal);
     }
   }
@@ -985,41 +990,46 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int
   const unsigned keep_from = theta + 1u;                 // plus the theta-valued entries up to idx_cut
   TOPP_STAMP(8);   // fit, theta
 
-  // ---- kept entries to the front of each region, their keys with gathered noise, top-n per wave -------------------------------
-  unsigned kept_w = 0;
-  for (unsigned i0 = 0; i0 < cnt; i0 += 64) {
-    const unsigned i = i0 + lane;
-    const u64 ent = i < cnt ? region[i] : 0ull;
-    const bool kept = i < cnt && ((unsigned)ent >= keep_from || ((unsigned)ent == theta && (int)(uint32_t)(ent >> 32) <= idx_cut));
-    const unsigned long long bal = __ballot(kept);
-    const unsigned pos = kept_w + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the chunk is in registers before its slots are overwritten
-    if (kept) region[pos] = ent;
-    kept_w += (unsigned)__popcll(bal);
+  // ---- the noise of the listed elements, from the registers it was streamed into: the listing pass is walked again (same
+  // ballots, so the same positions) and each thread drops the noise of its own entries beside them in LDS.  (Round 2 gathered
+  // e[index] for the kept entries from global memory instead: one 64-byte sector from HBM per entry, of a line the stream of
+  // the same row had already passed through - 1.38 x the algorithmic traffic, profiles/r2_pmc_topp.json; now 1.00 x.)
+  float* nz = noise_l + wave * TOPP_REGION;
+  unsigned walked = 0;
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const unsigned mc = (unsigned)(listed >> (4 * c)) & 15u;
+    if (__ballot(mc != 0u) == 0) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool hit = (mc >> j) & 1u;
+      const unsigned long long bal = __ballot(hit);
+      if (bal == 0) continue;
+      if (hit) nz[walked + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = en[c][j];     // (mine <= TOPP_REGION: a longer list gave up above)
+      walked += (unsigned)__popcll(bal);
+    }
   }
-  if (lane == 0) atomicAdd(&sh_kept, kept_w);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ---- keys of the kept entries, top-n per wave: four entries per lane ----------------------------------------------------------
   WaveList wl;
   wl.init(n, lane);
-  for (unsigned i0 = 0; i0 < kept_w; i0 += 256) {      // four entries per lane with their noise loads in flight together
-    u64 ent[4];
-    float ev[4];
+  unsigned kept_w = 0;
+  for (unsigned i0 = 0; i0 < cnt; i0 += 256) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned i = i0 + k * 64 + lane;
-      ent[k] = i < kept_w ? region[i] : 0ull;
-      ev[k] = i < kept_w ? e[(uint32_t)(ent[k] >> 32)] : 1.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+      const u64 ent = i < cnt ? region[i] : 0ull;
+      const bool kept = i < cnt && ((unsigned)ent >= keep_from || ((unsigned)ent == theta && (int)(uint32_t)(ent >> 32) <= idx_cut));
+      kept_w += (unsigned)__popcll(__ballot(kept));
       u64 it = 0;
-      if (i0 + k * 64 + lane < kept_w) {
-        it = make_item((__uint_as_float((uint32_t)ent[k]) / mass) / ev[k], (uint32_t)(ent[k] >> 32));
+      if (kept) {
+        it = make_item((__uint_as_float((uint32_t)ent) / mass) / nz[i], (uint32_t)(ent >> 32));
         it = it > wl.tau ? it : 0;
       }
       wl.offer_best(it);
     }
   }
+  if (lane == 0) atomicAdd(&sh_kept, kept_w);
   // the streamed noise: a dropped token's key is (+0 / mass) / e = +0 unless e is 0 or NaN
   bool abnormal = false;
 #pragma unroll
