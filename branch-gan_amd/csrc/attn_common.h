@@ -282,7 +282,7 @@ template <int DH> struct RowFrag<float, DH> {
   }
 };
 template <int DH> struct RowFrag<bf16_t, DH> {
-  static constexpr bool IN_REGS = (DH <= 128);
+  static constexpr bool IN_REGS = (DH <= 256);      // Dh 256: 64 registers per fragment, at one wave per SIMD (512 registers a lane) cheaper than a global re-read per tile
   bf16x8 v[IN_REGS ? DH / 16 : 1];
   const bf16_t* p;
   __device__ __forceinline__ void load(const bf16_t* row, bool valid, int h) {
