@@ -106,6 +106,19 @@ def causal_attention_core(q, k, v, scale, return_weights=False, p_drop=0.0):
     return out, ops.branch_attention_weights(q, k, ctx, [], [[]], scale, lse, drop=drop).to(v.dtype)
 
 
+def apply_head_mask(out, weights, head_mask, n_head):
+    """`attn_weights = attn_weights * head_mask` (NeoXNonResidualAttention.py:221-222, NonResidualAttention.py:161-162) for the
+    per-head masks HuggingFace's get_head_mask produces ((H,), (1, H, 1, 1): one factor per head): scaling a head's weights
+    scales that head's output, so the fused kernel's output (B, H, T, Dh) - and the weights, when they were asked for - are
+    multiplied instead.  Masks that vary inside a head would need the weights themselves: not supported."""
+    if head_mask is None:
+        return out, weights
+    if head_mask.numel() not in (1, n_head):
+        raise NotImplementedError("head_mask must hold one factor per head ((H,) or (1, H, 1, 1))")
+    hm = head_mask.reshape(1, -1, 1, 1)
+    return out * hm.to(out.dtype), (weights * hm.to(weights.dtype) if weights is not None else None)
+
+
 def dropout_active(model, dropoutRate=None):
     """Does a forward of `model` (an LM of either family, or a wrapper holding one) draw dropout masks?  GPT-2: the embedding,
     attention-probability and attention-output dropouts are always on (F.dropout without a training flag, quirk 1) at
@@ -173,21 +186,21 @@ class NeoXNonResidualAttention(nn.Module):
                                   customCasualMask=None, dropoutRate=None, output_attentions=False):
         """Reference signature (:183-184); dropoutRate is accepted and ignored there too.  The reference always returns the
         (B,H,K,C+1) weights; here they are formed only under output_attentions=True, else None."""
-        if head_mask is not None:
-            raise NotImplementedError("head_mask is not supported on the fused path")
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
         p = self._p_drop()
         if output_attentions:
-            return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, return_weights=True, p_drop=p)
-        return branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, p_drop=p), None
+            out, w = branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, return_weights=True, p_drop=p)
+        else:
+            out, w = branch_attention_core(query, key, value, lp, 1.0 / self.norm_factor, p_drop=p), None
+        return apply_head_mask(out, w, head_mask, self.num_attention_heads)
 
     def _p_drop(self):
         return self.attention_dropout if self.training else 0.0
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, head_mask=None, layer_past=None,
                 use_cache=False, output_attentions=False, isNonResidual=False, textualPast=None, customCasualMask=None):
-        if layer_past is not None or attention_mask is not None or head_mask is not None:
-            raise NotImplementedError("layer_past / attention_mask / head_mask are not on the branch hot path")
+        if layer_past is not None or attention_mask is not None:
+            raise NotImplementedError("layer_past / attention_mask are not on the branch hot path")
         B, T, _ = hidden_states.shape
         qkv = self.query_key_value(hidden_states)
         cos, sin = rope_tables(self.rotary_ndims, self.config.max_position_embeddings, self.config.rotary_emb_base, qkv.device)
@@ -203,6 +216,7 @@ class NeoXNonResidualAttention(nn.Module):
                 attn_output, weights = attn_output
         else:
             attn_output, weights = causal_attention_core(query, key, value, scale, return_weights=output_attentions, p_drop=self._p_drop())
+        attn_output, weights = apply_head_mask(attn_output, weights, head_mask, self.num_attention_heads)
         attn_output = attn_output.permute(0, 2, 1, 3).reshape(B, T, self.hidden_size)
         attn_output = self.dense(attn_output)
         outputs = (attn_output, present)
@@ -513,20 +527,20 @@ class GPT2NonResidualAttention(nn.Module):
     def nonResidualTextAttention(self, query, key, value, textualKeyPast, textualValuePast, head_mask=None,
                                  customCasualMask=None, dropoutRate=None, output_attentions=False):
         """Reference signature (:119-120); the weights only under output_attentions=True (else None)."""
-        if head_mask is not None:
-            raise NotImplementedError("head_mask is not supported on the fused path")
         lp = _legacy_layer_past((textualKeyPast, textualValuePast), customCasualMask, query.shape[-2], query.device)
         p = self._p_attn(dropoutRate)
         if output_attentions:
-            return branch_attention_core(query, key, value, lp, self._scale(), return_weights=True, p_drop=p)
-        return branch_attention_core(query, key, value, lp, self._scale(), p_drop=p), None
+            out, w = branch_attention_core(query, key, value, lp, self._scale(), return_weights=True, p_drop=p)
+        else:
+            out, w = branch_attention_core(query, key, value, lp, self._scale(), p_drop=p), None
+        return apply_head_mask(out, w, head_mask, self.num_heads)
 
     def forward(self, hidden_states, layer_past=None, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, use_cache=False, output_attentions=False, nonResidual=False,
                 nonResidualTextOnly=False, nonResdiaulPastOnly=False, promptPast=None, textualPast=None, promptMask=None,
                 customCasualMask=None, dropoutRate=None):
         if nonResidual or nonResdiaulPastOnly or promptPast is not None or encoder_hidden_states is not None or \
-                layer_past is not None or attention_mask is not None or head_mask is not None:
+                layer_past is not None or attention_mask is not None:
             raise NotImplementedError()      # the reference raises for `nonResidual` too (:265-266); prompt modes are out of scope
         p_attn = self._p_attn(dropoutRate)
         B, T, _ = hidden_states.shape
@@ -541,6 +555,7 @@ class GPT2NonResidualAttention(nn.Module):
                 attn_output, weights = attn_output
         else:
             attn_output, weights = causal_attention_core(query, key, value, self._scale(), return_weights=output_attentions, p_drop=p_attn)
+        attn_output, weights = apply_head_mask(attn_output, weights, head_mask, self.num_heads)
         attn_output = self.c_proj(attn_output.permute(0, 2, 1, 3).reshape(B, T, self.embed_dim))
         p = self._p_resid(dropoutRate)
         if p:
@@ -749,10 +764,44 @@ class NonResidualDiscriminatorWithDualValueHeads(nn.Module):
         inputValuePreds = torch.sigmoid(self.inputValueHead(hidden))
         return torch.sigmoid(pred.logits.squeeze(-1)), inputValuePreds, alterationsValuePreds
 
+    # ---- the legacy single-step path (Discriminator.py:28-79,112-127): text pass, then every alteration sequence of a sample
+    # against that sample's text keys / values under the default branch mask (row i sees text j < i and itself).  The train
+    # step uses the tree path; this is kept for the reference's call surface.
+    @staticmethod
+    def copyTextualPastToFitAlterations(textualPast, numAlterationsPerSample):
+        if numAlterationsPerSample <= 1:
+            return textualPast
+        return [(torch.repeat_interleave(k, numAlterationsPerSample, dim=0), torch.repeat_interleave(v, numAlterationsPerSample, dim=0))
+                for k, v in textualPast]
+
+    def generateTextualPrediction(self, textualIDs):
+        textualPrediction = self.nonResidualModel(input_ids=textualIDs, use_cache=True)
+        return textualPrediction, textualPrediction.past_key_values
+
+    def generateAlterationPrediction(self, textualPast, alternationIDs):
+        stacked = alternationIDs.reshape(alternationIDs.shape[0] * alternationIDs.shape[1], alternationIDs.shape[2])
+        past = self.copyTextualPastToFitAlterations(textualPast, alternationIDs.shape[1])
+        return self.nonResidualModel(input_ids=stacked, textualPast=[(k, v) for k, v in past])
+
+    def finalizeDiscForward(self, textualPrediction, nonResPrediction, alternationIDs):
+        txtDiscPreds, txtInputValuePreds, txtAlterationsValuePreds = self._finalizeSinglePrediction(textualPrediction)
+        _, altInputValuePreds, altAlterationsValuePreds = self._finalizeSinglePrediction(nonResPrediction)
+        shape = alternationIDs.shape
+        altDiscPreds = torch.sigmoid(nonResPrediction.logits.reshape(shape))
+        return txtDiscPreds, altDiscPreds, {'txtInputPreds': txtInputValuePreds, 'txtAlterationsPreds': txtAlterationsValuePreds,
+                                            'altInputPreds': altInputValuePreds.reshape(shape),
+                                            'altAlterationsPreds': altAlterationsValuePreds.reshape(shape)}
+
+    def discForward(self, textualIDs, alternationIDs):
+        """textualIDs (B, S); alternationIDs (B, n, S) -> (text predictions (B, S), alteration predictions (B, n, S), value heads)."""
+        textualPrediction, textualPast = self.generateTextualPrediction(textualIDs)
+        nonResPrediction = self.generateAlterationPrediction(textualPast, alternationIDs)
+        return self.finalizeDiscForward(textualPrediction, nonResPrediction, alternationIDs)
+
     def forward(self, inputArgs, doDiscForward=True, doTransformerPass=False, doFinalizeSinglePrediction=False,
                 doTransformerPassWithPrediction=False):
         if doDiscForward:
-            raise NotImplementedError("the legacy single-step discForward is superseded by the tree path")
+            return self.discForward(**inputArgs)
         if doTransformerPass:
             return self.nonResidualModel(**inputArgs)
         if doTransformerPassWithPrediction:

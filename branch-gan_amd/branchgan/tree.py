@@ -31,13 +31,27 @@ class PredictionTreeNode:
     def __init__(self, ids, parent=None, depth=0, beam=0, probs=None, isRandom=False, sparseIndex=None, rootSeqSize=None,
                  discPreds=None, valueHeadData=None, logProbs=None):
         self.isRandom, self.parent, self.children = isRandom, parent, []
-        self.depth, self.probs, self.logProbs, self.beam, self.ids = depth, probs, logProbs, beam, ids
+        self.depth, self._probs, self.logProbs, self.beam, self.ids = depth, probs, logProbs, beam, ids
         self.numPredictionIDs = ids.shape[1]
         self.sparseIndex = sparseIndex
         self.rootSeqSize = ids.shape[1] if depth == 0 else rootSeqSize
         self.valueHeadData, self.discPreds = valueHeadData, discPreds
         self.attMask = None
         self.past = None
+
+    @property
+    def probs(self):
+        """Probabilities of this node's tokens (the reference stores them; here they are exp(logProbs), formed when somebody
+        asks - the train step works from the log probabilities and never does)."""
+        if callable(self._probs):
+            self._probs = self._probs()
+        elif self._probs is None and self.logProbs is not None:
+            self._probs = self.logProbs.exp()
+        return self._probs
+
+    @probs.setter
+    def probs(self, value):
+        self._probs = value
 
     def addGeneratorPredictionToNode(self, ids, past, attMask, probs, isRandomSamples=None, logProbs=None):
         self.past, self.attMask = past, attMask
@@ -252,7 +266,7 @@ def _branch_step(generator, node, device, dropoutRate, numAlterations, strat, pa
 def _set_child_log_probs(node, lp):
     for j, child in enumerate(node.children):
         child.logProbs = lp[:, :, j]
-        child.probs = child.logProbs.exp()
+        child.probs = None                                  # lazily exp(logProbs)
 
 
 _row_map_cache = {}
@@ -346,12 +360,12 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
     _, logp = ops.softmax_stats(logits, gather)
     labelLogProbs = logp[:, :-1, 0]                                                      # (B, S-1)
     altLogProbs = logp[:, sparseIndex, 1:]                                               # (B, K, n0)
-    inputProbs = torch.cat((torch.zeros(B, 1, device=device), labelLogProbs.exp()), dim=-1)
+    inputProbs = lambda: torch.cat((torch.zeros(B, 1, device=device), labelLogProbs.exp()), dim=-1)     # formed on request
 
     root = PredictionTreeNode(inputIDs, sparseIndex=sparseIndex, probs=inputProbs)
     root.labelLogProbs = labelLogProbs
     randomNodeInfo = getRandomNodesFromRule(firstRule.samplingStrategy, firstRule.samplingParams, n0)
-    root.addGeneratorPredictionToNode(sparseAltIDs, firstOutput.prediction.past_key_values, None, altLogProbs.exp(),
+    root.addGeneratorPredictionToNode(sparseAltIDs, firstOutput.prediction.past_key_values, None, None,
                                       isRandomSamples=randomNodeInfo, logProbs=altLogProbs)
 
     # Sampling is sequential by depth, differentiation is not: the branch forwards below run WITHOUT autograd (they only have
@@ -377,14 +391,14 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
             with torch.no_grad() if deferred else contextlib.nullcontext():
                 lp, past, altIDs = _branch_step(generator, node, device, rule.samplingParams.get('dropoutRate', None),
                                                 numAlterations, strat, params, noise_fn)
-            node.addGeneratorPredictionToNode(altIDs, past, None, lp.exp(), getRandomNodesFromRule(strat, params, numAlterations),
+            node.addGeneratorPredictionToNode(altIDs, past, None, None, getRandomNodesFromRule(strat, params, numAlterations),
                                               logProbs=lp)
             forwarded.append(node)
     if pending and len(forwarded) + len(pending) > ops.MAX_SLOTS:          # too many nodes for one pass: a branch step each
         for node, strat, params, numAlterations in pending:
             with torch.no_grad():
                 lp, past, altIDs = _branch_step(generator, node, device, None, numAlterations, strat, params, noise_fn)
-            node.addGeneratorPredictionToNode(altIDs, past, None, lp.exp(), getRandomNodesFromRule(strat, params, numAlterations),
+            node.addGeneratorPredictionToNode(altIDs, past, None, None, getRandomNodesFromRule(strat, params, numAlterations),
                                               logProbs=lp)
             forwarded.append(node)
         pending = []

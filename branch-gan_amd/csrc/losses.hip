@@ -212,50 +212,93 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_loss_kernel(RlArgs a) {
 // A zone whose mask is empty reports 0 (the reference's `if x.sum() > 0 else 0`).
 constexpr int RL_DIAG_ACC = 26;
 
+// One workgroup, a few KB of input: the kernel's time is its dependent global round trips, so every loop below takes its
+// elements U at a time with all their loads issued before the first use (8 rounds of loads -> 3: 87 -> ~20 us at configs[1]).
+// The padded columns j >= K of the alteration rows do not depend on the node: once per (b, j), weighted by N.
 __global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
   __shared__ float red[RL_DIAG_ACC * 16];
   const bg_rl_loss_shape& s = a.sh;
   const int tid = threadIdx.x;
+  constexpr int U = 4;
   // [z]: input loss sum, input count over S-1, input advantage sum, input count over S  (z = A, B, C)
   // [12 + z]: alteration loss sum, count, advantage sum, count under the depth mask;  [24] heads correct, [25] input correct
   float acc[RL_DIAG_ACC];
 #pragma unroll
   for (int i = 0; i < RL_DIAG_ACC; ++i) acc[i] = 0.f;
-  for (int i = tid; i < s.B * s.S; i += LOSS_THREADS) {
-    const int b = i / s.S, t = i % s.S;
-    const float in_h = a.in_head[i], alt_h = a.alt_head[i];
-    const float score = t + 1 < s.S ? a.in[i + 1] : 0.f;
-    const Adv ad = advantage(s, score, in_h, alt_h, s.ignore_input != 0);
-    const bool za = score >= in_h, above = score >= alt_h;
-    const bool zone[3] = {za, za != above, !above};
-    float loss = 0.f, dv;
-    if (t < s.S - 1) rl_term(s.probs_input != 0, a.label_lp[b * (s.S - 1) + t], ad, loss, dv);
-#pragma unroll
-    for (int z = 0; z < 3; ++z)
-      if (zone[z]) {
-        if (t < s.S - 1) { acc[4 * z] += loss; acc[4 * z + 1] += 1.f; }
-        acc[4 * z + 2] += ad.adv;
-        acc[4 * z + 3] += 1.f;
-      }
-    acc[24] += alt_h >= in_h ? 0.f : 1.f;
-    acc[25] += a.in[i] >= alt_h ? 1.f : 0.f;
-  }
-  for (int i = tid; i < s.B * s.N * s.S; i += LOSS_THREADS) {
-    const int j = i % s.S, n = (i / s.S) % s.N, b = i / (s.S * s.N);
-    const bool real = j < s.K;
-    const int64_t e = ((int64_t)b * s.N + n) * s.K + j;
-    const float score = real ? a.alt[e] : 0.f;
-    const float in_h = a.in_head[b * s.S + j], alt_h = a.alt_head[b * s.S + j];
+  auto add_alt = [&](float score, float in_h, float alt_h, bool real, float lp, float m, float weight) {
     const Adv ad = advantage(s, score, in_h, alt_h, s.ignore_alt != 0);
     const bool za = score >= in_h, above = score >= alt_h;
     const bool zone[3] = {za, za != above, !above};
     float loss, dv;
-    if (real) rl_term(s.probs_input != 0, a.alt_lp[e], ad, loss, dv);
+    if (real) rl_term(s.probs_input != 0, lp, ad, loss, dv);
     else rl_term(true, 1e-5f, ad, loss, dv);
-    const float m = (s.use_depth_mask && real) ? a.mask[n * s.K + j] : 0.f;
 #pragma unroll
     for (int z = 0; z < 3; ++z)
-      if (zone[z]) { acc[12 + 4 * z] += loss; acc[12 + 4 * z + 1] += 1.f; acc[12 + 4 * z + 2] += ad.adv; acc[12 + 4 * z + 3] += m; }
+      if (zone[z]) { acc[12 + 4 * z] += weight * loss; acc[12 + 4 * z + 1] += weight; acc[12 + 4 * z + 2] += weight * ad.adv; acc[12 + 4 * z + 3] += m; }
+  };
+  // ---- the input row: (b, t) over B x S -------------------------------------------------------------------------------------
+  const int n_in_el = s.B * s.S;
+  for (int i0 = tid; i0 < n_in_el; i0 += U * LOSS_THREADS) {
+    float in_h[U], alt_h[U], score[U], own[U], lp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u * LOSS_THREADS, n_in_el - 1);
+      const int b = i / s.S, t = i % s.S;
+      in_h[u] = a.in_head[i]; alt_h[u] = a.alt_head[i]; own[u] = a.in[i];
+      score[u] = a.in[min(i + 1, n_in_el - 1)];
+      lp[u] = a.label_lp[b * (s.S - 1) + min(t, s.S - 2)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * LOSS_THREADS;
+      if (i >= n_in_el) break;
+      const int t = i % s.S;
+      const float sc = t + 1 < s.S ? score[u] : 0.f;
+      const Adv ad = advantage(s, sc, in_h[u], alt_h[u], s.ignore_input != 0);
+      const bool za = sc >= in_h[u], above = sc >= alt_h[u];
+      const bool zone[3] = {za, za != above, !above};
+      float loss = 0.f, dv;
+      if (t < s.S - 1) rl_term(s.probs_input != 0, lp[u], ad, loss, dv);
+#pragma unroll
+      for (int z = 0; z < 3; ++z)
+        if (zone[z]) {
+          if (t < s.S - 1) { acc[4 * z] += loss; acc[4 * z + 1] += 1.f; }
+          acc[4 * z + 2] += ad.adv;
+          acc[4 * z + 3] += 1.f;
+        }
+      acc[24] += alt_h[u] >= in_h[u] ? 0.f : 1.f;
+      acc[25] += own[u] >= alt_h[u] ? 1.f : 0.f;
+    }
+  }
+  // ---- the alteration rows, real columns: (b, n, j < K) --------------------------------------------------------------------------
+  const int n_real = s.B * s.N * s.K;
+  for (int i0 = tid; i0 < n_real; i0 += U * LOSS_THREADS) {
+    float in_h[U], alt_h[U], score[U], lp[U], m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = min(i0 + u * LOSS_THREADS, n_real - 1);
+      const int j = e % s.K, n = (e / s.K) % s.N, b = e / (s.K * s.N);
+      score[u] = a.alt[e]; lp[u] = a.alt_lp[e];
+      in_h[u] = a.in_head[b * s.S + j]; alt_h[u] = a.alt_head[b * s.S + j];
+      m[u] = s.use_depth_mask ? a.mask[n * s.K + j] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * LOSS_THREADS < n_real) add_alt(score[u], in_h[u], alt_h[u], true, lp[u], m[u], 1.f);
+  }
+  // ---- their padded columns (score 0, probability 1e-5, outside the depth mask): (b, K <= j < S), the same for every node ----------
+  const int pad = s.S - s.K, n_pad = s.B * pad;
+  for (int i0 = tid; i0 < n_pad; i0 += U * LOSS_THREADS) {
+    float in_h[U], alt_h[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u * LOSS_THREADS, n_pad - 1);
+      const int b = i / pad, j = s.K + i % pad;
+      in_h[u] = a.in_head[b * s.S + j]; alt_h[u] = a.alt_head[b * s.S + j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * LOSS_THREADS < n_pad) add_alt(0.f, in_h[u], alt_h[u], false, 0.f, 0.f, (float)s.N);
   }
   float mask_sum = 0.f;
   if (s.use_depth_mask)

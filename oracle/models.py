@@ -139,3 +139,16 @@ def discriminator_forward(sd, cfg, input_ids, **kw):
     alt_v = torch.sigmoid(F.linear(hidden, sd["discriminator.alterationsValueHead.weight"],
                                    sd["discriminator.alterationsValueHead.bias"]))
     return pred, in_v, alt_v, presents
+
+
+def discriminator_forward_legacy(sd, cfg, text_ids, alteration_ids):
+    """The single-step `discForward` of the dual-head discriminator (Discriminator.py:28-79,112-127): the text pass, then
+    every alteration sequence (B, n, S), stacked to (B*n, S), against its sample's text keys / values repeated n times, under
+    the default branch mask (customCasualMask None).  -> (text preds (B,S), alteration preds (B,n,S), dict of the four value
+    head tensors)."""
+    txt_pred, txt_in, txt_alt, presents = discriminator_forward(sd, cfg, text_ids)
+    B, n, S = alteration_ids.shape
+    past = [(torch.repeat_interleave(k, n, dim=0), torch.repeat_interleave(v, n, dim=0)) for k, v in presents]
+    alt_pred, alt_in, alt_alt, _ = discriminator_forward(sd, cfg, alteration_ids.reshape(B * n, S), textual_past=past)
+    return txt_pred, alt_pred.reshape(B, n, S), {"txtInputPreds": txt_in, "txtAlterationsPreds": txt_alt,
+                                                 "altInputPreds": alt_in.reshape(B, n, S), "altAlterationsPreds": alt_alt.reshape(B, n, S)}
