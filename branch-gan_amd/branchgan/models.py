@@ -225,7 +225,7 @@ class NeoXNonResidualAttention(nn.Module):
         return outputs
 
 
-def _neox_fused_attention(at, h1, pos, dtype, lp):
+def _neox_fused_attention(at, h1, pos, dtype, lp, dense_bias_grad=True):
     """NeoXNonResidualAttention.forward (:90-148) on the fused path: projections through fused.linear (cached bf16 weights,
     in-place fp32 dW / bias gradients), split + rotary in one kernel, branch / causal attention kernel."""
     B, T, _ = h1.shape
@@ -241,7 +241,8 @@ def _neox_fused_attention(at, h1, pos, dtype, lp):
     else:
         out, _ = ops.causal_attention(query, key, value, scale=scale, drop=ops.drop_descriptor(at._p_drop()))
     out = out.permute(0, 2, 1, 3).reshape(B, T, at.hidden_size)        # (into the x stack by copy_: autograd's CopySlices costs more than the stack copy)
-    return fused.linear(out, at.dense.weight, at.dense.bias, "oi", dtype), (key, value)
+    # dense_bias_grad=False: the LayerNorm backward that follows the residual add produces the bias gradient (add_layer_norm(delta_bias=))
+    return fused.linear(out, at.dense.weight, at.dense.bias, "oi", dtype, bias_grad=dense_bias_grad), (key, value)
 
 
 class GPTNeoXMLP(nn.Module):
@@ -302,7 +303,7 @@ class GPTNeoXLayer(nn.Module):
             x1, h1 = fused.add_layer_norm(x, delta[0], self.input_layernorm, dtype, delta_b=delta[1], out_for=qkv_w)
         else:
             x1, h1 = fused.add_layer_norm(x, delta, self.input_layernorm, dtype, out_for=qkv_w)
-        a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp)
+        a, present = _neox_fused_attention(self.attention, h1, pos, dtype, lp, dense_bias_grad=self.drops())
         if self.drops():      # a dropout between the projection and the residual add: the LayerNorm backward's shortcuts do not apply
             x2, h2 = fused.add_layer_norm(x1, self._drop(a), self.post_attention_layernorm, dtype, out_for=up_w)
         else:

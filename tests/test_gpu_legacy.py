@@ -65,3 +65,33 @@ def test_legacy_disc_forward_matches_the_oracle(family):
     (alt.mean() + txt.mean()).backward()
     assert all(torch.isfinite(p.grad).all() for p in disc.parameters() if p.grad is not None)
     assert disc.nonResidualModel.valueHead.weight.grad.abs().sum() > 0
+
+
+def test_neox_sequential_residual_block_on_the_fused_path():
+    """use_parallel_residual=False (no Pythia config uses it): the attention projection's bias gradient comes from the LayerNorm
+    backward behind the residual add, and only from there - round 3 found it counted twice.  Every gradient of the fused path
+    against the module-by-module path."""
+    import dataclasses
+    from branchgan import configs, fused, models
+    torch.manual_seed(0)
+    cfg = dataclasses.replace(configs.LMConfig("gpt_neox", 101, 64, 2, 2, 48), use_parallel_residual=False)
+    lm = models.make_lm(cfg).cuda()
+    with torch.no_grad():
+        for p in lm.parameters():
+            p.mul_(3.0)
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    ids = torch.randint(0, 101, (2, 24)).cuda()
+    grads = {}
+    try:
+        for use in (True, False):
+            fused.ENABLED = use
+            lm.zero_grad()
+            lm(input_ids=ids, returnLmLogits=True).logits.float().square().mean().backward()
+            grads[use] = {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}
+    finally:
+        fused.ENABLED = True
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, n
