@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) 
 
 template <typename T> int launch_bwd_split(const AttnArgs& a, hipStream_t st);      // attn_bwd_split.hip: 0 no, 1 slots left, 2 all
 bool attn_bwd_covers_dropout(const bg_attn_shape& sh);                                // attn_bwd_split.hip
+bool launch_bwd_head(const AttnArgs& a, hipStream_t st);                              // attn_bwd_head.hip: short sequences, a head per workgroup
 
 template <typename T>
 static void launch_slots(const AttnArgs& a, hipStream_t st) {
@@ -358,6 +359,7 @@ static void launch_slots(const AttnArgs& a, hipStream_t st) {
 template <typename T>
 static void launch_bwd(const AttnArgs& a, hipStream_t st) {
   const bg_attn_shape& sh = a.sh;
+  if (launch_bwd_head(a, st)) return;                  // the whole head in one CU's LDS (bf16, Dh <= 64, short sequences)
   if (const int done = launch_bwd_split<T>(a, st)) {   // the other axis split over the waves; one launch where it fits
     if (done == 1) launch_slots<T>(a, st);
     return;

@@ -243,3 +243,50 @@ def test_key_range_split_forward_equals_unsplit(dtype, Dh, B, H):
     tol = 2e-6 if dtype == torch.float32 else 1.6e-2          # bf16: one rounding of the output, at most one ulp apart
     np.testing.assert_allclose(o1.numpy(), o0.numpy(), atol=tol)
     np.testing.assert_allclose(l1.numpy(), l0.numpy(), atol=2e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("S,Dh,B,H", [(256, 64, 8, 12), (200, 64, 1, 3), (512, 32, 1, 4), (96, 64, 8, 12), (200, 32, 8, 8)])
+def test_bf16_root_causal_backward_head_resident(S, Dh, B, H):
+    """bf16 root causal pass at short sequences against the oracle on the same bf16-rounded inputs.  With at least 64 heads the
+    backward is the head-resident kernel (attn_bwd_head.hip: the whole (batch, head) in one CU's LDS; configs[1]'s 96 heads at
+    S 256, 96 at S 96, 64 at S 200 / Dh 32 with ragged last tiles), below that the one-launch kernel; BRANCHGAN_ATTN_BWD_HEAD=2
+    sends every case that fits (S 512 at Dh 32 fills the LDS) through the head-resident one."""
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(S + Dh)
+    q, k, v, go = [torch.randn(B, H, S, Dh, generator=gen).bfloat16().float() for _ in range(4)]
+    lv = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o_ref, _ = A.causal_attention(A.NEOX, *lv)
+    g_ref = torch.autograd.grad(o_ref, lv, go)
+    ld = [t.bfloat16().cuda().requires_grad_(True) for t in (q, k, v)]
+    o, _ = ops.causal_attention(*ld)
+    g = torch.autograd.grad(o, ld, go.bfloat16().cuda())
+    np.testing.assert_allclose(o.detach().float().cpu().numpy(), o_ref.detach().numpy(), atol=3e-2)
+    for a, b_, name in zip(g, g_ref, "qkv"):
+        np.testing.assert_allclose(a.float().cpu().numpy(), b_.numpy(), atol=6e-2, err_msg="d" + name)   # up to S rows sum into a dK / dV row
+        rel = float((a.float().cpu() - b_).norm() / b_.norm())
+        assert rel < 1e-2, (name, rel)
+
+
+@pytest.mark.parametrize("K", [7, 40])
+def test_bf16_multi_node_tree_backward_matches_fp32_kernels(K):
+    """The branching tree of test_multi_node_tree_one_pass_equals_node_by_node in bf16 (head-resident backward: dQ tiles with
+    branch keys, text dK / dV, slot rows of shared ancestors) against the fp32 kernels on the same rounded inputs."""
+    from branchgan import ops
+    gen = torch.Generator().manual_seed(3)
+    B, H, Dh, S = 2, 2, 64, 50 if K == 7 else 130
+    sparse = torch.tensor([0, 3, 10, 11, 30, 40, 48]) if K == 7 else torch.from_numpy(np.sort(np.random.RandomState(5).choice(S - 1, K, replace=False)))
+    ctx_len = (sparse + 1).int().cuda()
+    paths = [[0], [0, 1], [2], [2, 3], [2, 4]]
+    N = len(paths)
+    mk = lambda *s: torch.randn(*s, generator=gen).bfloat16()
+    q, kt, vt = mk(B, H, N, K, Dh), mk(B, H, S, Dh), mk(B, H, S, Dh)
+    ks, vs = [mk(B, H, K, Dh) for _ in range(N)], [mk(B, H, K, Dh) for _ in range(N)]
+    gout = mk(B, H, N, K, Dh)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        leaves = [t.to(dt).cuda().requires_grad_(True) for t in [q, kt, vt] + ks + vs]
+        out, _ = ops.branch_attention(leaves[0], leaves[1], leaves[2], ctx_len, leaves[3:3 + N], leaves[3 + N:], paths=paths)
+        res[dt] = [out.detach().float().cpu()] + [g.float().cpu() for g in torch.autograd.grad(out, leaves, gout.to(dt).cuda())]
+    for i, (a, b_) in enumerate(zip(res[torch.bfloat16], res[torch.float32])):
+        np.testing.assert_allclose(a.numpy(), b_.numpy(), atol=4e-2 if i in (2, 3) else 3e-2, err_msg=f"tensor {i}")
+        assert float((a - b_).norm() / b_.norm()) < 1e-2, i
