@@ -402,6 +402,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    launch_notes = {}
+
     def run(dtype_name, steps, warmup, with_rooflines):
         """Builds the models fresh and times `steps` steps; -> (elapsed s, final losses, roofline objects)."""
         use_amp = dtype_name == "bf16"
@@ -415,8 +417,24 @@ def main():
             step = eager_step
         else:
             from branchgan.graphs import GraphedTrainStep
-            graphed = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, torch.bfloat16 if use_amp else None)
-            step = lambda i: graphed.step(data[i % n_batches], i)
+            failure = None
+            try:
+                graphed = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, torch.bfloat16 if use_amp else None)
+            except Exception as exc:        # noqa: BLE001 - a capture that fails must not take the measurement with it
+                failure = f"{type(exc).__name__}: {exc}"[:300]
+                graphed = None
+            if world > 1:                   # every rank runs the same form of the step, or their collectives do not meet
+                flag = torch.tensor([1 if failure else 0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) and graphed is not None:
+                    failure, graphed = "another rank could not capture its step", None
+            if graphed is None:
+                print(f"[bench] rank {rank}: HIP-graph capture of the step failed ({failure}); timing the eager step instead", file=sys.stderr)
+                launch_notes[dtype_name] = f"eager (graph capture failed: {failure})"
+                torch.cuda.synchronize()
+                step = eager_step
+            else:
+                step = lambda i: graphed.step(data[i % n_batches], i)
         arena_optims = [o.optimizer for o in (g_opt, d_opt) if hasattr(o.optimizer, "timing")]
         elapsed, d, g = measure_steps(step, steps, warmup, fence, arena_optims)
         if graphed is not None:
@@ -466,7 +484,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": main_dtype, "data": "synthetic",
         "config": {"workload": wl["name"], "per_gpu_batch": B, "seq_len": S, "branch_points": wl["K"], "depth": wl["D"],
-                   "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay of fwd+bwd; all-reduce and Adam eager",
+                   "generator": wl["gen"], "discriminator": wl["disc"], "parallelism": f"dp{world}", "launch": "eager" if args.eager else launch_notes.get(main_dtype, "hipGraph replay of fwd+bwd; all-reduce and Adam eager"),
                    "precision": "bf16 autocast, fp32 master weights and accumulation" if use_amp else "fp32",
                    "weights": "random init", "gemm": "hipBLASLt, recorded TunableOp choices" if tuned else "hipBLASLt defaults", "final_losses": losses},
         # the dominant hand-written hot-path entry point: attention backward; the forward and the optimizer kernel beside it
