@@ -336,7 +336,10 @@ template <typename T, int DH>
 __global__ __launch_bounds__(256) void branch_attn_bwd_slots_kernel(AttnArgs a) {
   __shared__ int s_members[256];
   __shared__ int s_count[ATT_WAVES];
-  bwd_slot_rows<T, DH, false>(a, s_members, s_count, blockIdx.x, blockIdx.y);
+  // the slots of one head read the same member rows (q, dO of the nodes on whose path they lie): one XCD, one L2 fetch
+  // (c4's tree pass: 88.7 MB of HBM traffic per dispatch with the slots dealt over the eight XCDs, profiles/r3_pmc_attn_bwd_c4.json)
+  const BlockXY blk = xcd_block();
+  bwd_slot_rows<T, DH, false>(a, s_members, s_count, blk.x, blk.y);
 }
 
 template <typename T> int launch_bwd_split(const AttnArgs& a, hipStream_t st);      // attn_bwd_split.hip: 0 no, 1 slots left, 2 all

@@ -92,7 +92,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void branch_attn_bwd_head_kernel(Head
   int* reach_l = (int*)(smem + L.reach);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
-  const int part = blockIdx.x, bh = blockIdx.y, b = bh / sh.H, hh = bh % sh.H;
+  // the parts of one head on ONE XCD (blocks are dealt round-robin over the 8 XCDs, each with an L2 of its own): the second part
+  // then finds the head in L2: 45.3 -> 28.8 MB of HBM traffic per launch at configs[1] (25.2 MB algorithmic; rocprofv3 --pmc
+  // FETCH_SIZE / WRITE_SIZE, benchmarks/probes/pmc_attention.sh), 17.6 -> 17.0 us
+  const BlockXY blk = xcd_block();
+  const int part = blk.x, bh = blk.y, b = bh / sh.H, hh = bh % sh.H;
   const int R = sh.NQ * sh.K, S = sh.S_text;
   const int nq = L.rpad / ATT_TILE, nk = L.spad / ATT_TILE;
   const T* q_head = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh;
