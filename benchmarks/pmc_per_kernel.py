@@ -1,7 +1,8 @@
 import csv, glob, sys, collections
 csv.field_size_limit(1 << 30)
 def tot(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    import os
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] == counter and "attn" in row["Kernel_Name"]:

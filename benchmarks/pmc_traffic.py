@@ -19,7 +19,7 @@ def total(directory, counter, patterns):
     if not files:
         raise SystemExit(f"no counter_collection.csv under {directory}")
     kb, n, names = 0.0, 0, {}
-    with open(files[0], newline="") as fh:
+    with open(max(files, key=os.path.getmtime), newline="") as fh:      # the newest pass (gpurun merges earlier ones into the same tree)
         for row in csv.DictReader(fh):
             if row["Counter_Name"] != counter:
                 continue
