@@ -53,6 +53,11 @@ template <typename T, int DH, int DPASS> struct BwdSplitLds {
   static constexpr size_t OWN_BYTES = 2 * TILE_BYTES + ATT_TILE * 4;
   static constexpr bool OWN = STAGE_BYTES + OWN_BYTES + 20 * 1024 <= 160 * 1024;
   static constexpr size_t BYTES = STAGE_BYTES + (OWN ? OWN_BYTES : 0);
+  // bf16 Dh 256 (round 3): no room to KEEP the own tile in LDS, but the same coalesced fetch passes THROUGH the staging area
+  // before the loop needs it - every lane then lifts its row's fragments into registers (RowFrag::IN_REGS) and a second
+  // barrier hands the area back.  The trace at configs[3] showed 7-10 us of a 25 us workgroup life in the per-lane row reads
+  // this replaces (each load instruction touching 32-64 cache lines, four waves reading the same rows).
+  static constexpr bool PARK = !OWN && sizeof(T) == 2;
 };
 
 // Sum of the four waves' partial [d][row] tiles in `mo` (fp32, [wave][DPASS][32]) for this thread's (row, feature group).
@@ -131,11 +136,12 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
   TileRegs<T, DH, 64> kreg, vreg;
   typename std::conditional<SL::OWN, LdsRowFrag<T, DH>, RowFrag<T, DH>>::type qf, dof;   // own tile in LDS: read where used
   float delta;
-  if constexpr (SL::OWN) {
+  if constexpr (SL::OWN || SL::PARK) {
     constexpr int VEC = 16 / sizeof(T), CPR = DH / VEC;
-    T* q_l = (T*)(smem + SL::STAGE_BYTES);
-    T* do_l = (T*)(smem + SL::STAGE_BYTES + SL::TILE_BYTES);
-    float* delta_l = (float*)(smem + SL::STAGE_BYTES + 2 * SL::TILE_BYTES);
+    // OWN: behind the staging area, for the kernel's life; PARK: in wave 0's staging region (delta in wave 1's) until the loop
+    T* q_l = (T*)(smem + (SL::PARK ? 0 : SL::STAGE_BYTES));
+    T* do_l = (T*)(smem + (SL::PARK ? 0 : SL::STAGE_BYTES) + SL::TILE_BYTES);
+    float* delta_l = (float*)(smem + (SL::PARK ? SL::WAVE_BYTES : SL::STAGE_BYTES + 2 * SL::TILE_BYTES));
     const int row0 = tile_x * ATT_TILE;
     TileRegs<T, DH, 256> gq, gdo, go;
     gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, row0, tid);
@@ -163,18 +169,23 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
     gq.template store<true, false>(q_l, nullptr, tid);
     gdo.template store<true, false>(do_l, nullptr, tid);
     __syncthreads();
-    qf.load(q_l + (lane & 31) * Lds<T, DH>::RSTRIDE);
-    dof.load(do_l + (lane & 31) * Lds<T, DH>::RSTRIDE);
-    delta = delta_l[lane & 31];
+    if constexpr (SL::PARK) {
+      qf.load(q_l + (lane & 31) * Lds<T, DH>::RSTRIDE, true, h);
+      dof.load(do_l + (lane & 31) * Lds<T, DH>::RSTRIDE, true, h);
+      delta = delta_l[lane & 31];
+      __syncthreads();                                   // the staging regions are the waves' own again
+    } else {
+      qf.load(q_l + (lane & 31) * Lds<T, DH>::RSTRIDE);
+      dof.load(do_l + (lane & 31) * Lds<T, DH>::RSTRIDE);
+      delta = delta_l[lane & 31];
+    }
   } else {
     if (wave * ATT_TILE < sh.S_text) {
       kreg.load(kt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
       vreg.load(vt, sh.t_ss, wave * ATT_TILE, sh.S_text, lane);
     }
-    if constexpr (!SL::OWN) {
-      qf.load(q_row, valid, h);
-      dof.load(do_row, valid, h);
-    }
+    qf.load(q_row, valid, h);
+    dof.load(do_row, valid, h);
     delta = pair_dot<T, DH>(do_row, o_row, h, valid);
     if (wave == 0 && valid && h == 0) a.delta[stat] = delta;
   }
@@ -276,7 +287,8 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
 template <typename T, int DH, int DT0, int DT1, bool OWN_DELTA, bool DROP = false>
 __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int tile_x, int bh) {
   constexpr int DPASS = (DT1 - DT0) * 32;
-  constexpr bool PREFETCH = DH >= 128;
+  // (the full-width pass at Dh 256 holds 256 accumulator registers + 128 of K / V fragments: no room for a tile in flight)
+  constexpr bool PREFETCH = DH >= 128 && DPASS < 256;
   using SL = BwdSplitLds<T, DH, DPASS>;
   using L = Lds<T, DH>;
   const bg_attn_shape& sh = a.sh;
@@ -305,19 +317,24 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
   constexpr int VEC = 16 / sizeof(T);
   constexpr int CPR = DH / VEC;                          // 16-byte chunks per row
   constexpr int PERW = ATT_TILE * CPR / 64;              // chunks per lane
+  // the full-width pass at Dh 256 gathers a tile in two halves of 16 rows (64 registers in flight, not 128: with 256 of
+  // accumulators and 128 of K / V fragments the whole tile would spill)
+  constexpr int GPARTS = DPASS >= 256 ? 4 : 1;
+  constexpr int PERG = PERW / GPARTS;
   typedef typename TileRegs<T, DH, 64>::V Chunk;
-  Chunk gq[PERW], gd[PERW];
-  [[maybe_unused]] Chunk go[OWN_DELTA ? PERW : 1];
+  Chunk gq[PERG], gd[PERG];
+  [[maybe_unused]] Chunk go[OWN_DELTA ? PERG : 1];
   float g_lse = 0.f, g_delta = 0.f;
   int g_ctx = 0;
   const T* q_head = (const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh;
   const T* do_head = (const T*)a.dout + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh;
   [[maybe_unused]] const T* o_head = (const T*)a.out + (int64_t)b * sh.o_sb + (int64_t)hh * sh.o_sh;
-  auto gather = [&](int tq) __attribute__((always_inline)) {
+  auto gather_part = [&](int tq, auto part) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part)::value;
     const int q0 = tq * ATT_TILE;
 #pragma unroll
-    for (int i = 0; i < PERW; ++i) {
-      const int c = lane + i * 64;
+    for (int i = 0; i < PERG; ++i) {
+      const int c = lane + (PART * PERG + i) * 64;
       const int r = c / CPR, d0 = (c % CPR) * VEC;
       // rows past the end read the last row instead (no branch around the loads): their ctx is 0 below, which masks them
       const int rr = min(q0 + r, R - 1);
@@ -329,21 +346,24 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       gd[i] = *(const Chunk*)(do_head + ooff);
       if constexpr (OWN_DELTA) go[i] = *(const Chunk*)(o_head + ooff);
     }
-    const int rq = q0 + (lane & 31);
-    const bool qv = rq < R;
-    const int nn = qv ? rq / sh.K : 0, kk = qv ? rq % sh.K : 0;
-    const int64_t stat = ((int64_t)bh * sh.NQ + nn) * sh.K + kk;
-    g_ctx = qv ? min(a.ctx_len[kk], sh.S_text) : 0;      // 0 for rows past the end: masks everything
-    g_lse = qv ? a.lse[stat] : 0.f;
-    if constexpr (!OWN_DELTA) g_delta = qv ? a.delta[stat] : 0.f;
-    if constexpr (DROP) g_rkey = drop_row_key(drop, (uint32_t)rq);
+    if constexpr (PART == 0) {
+      const int rq = q0 + (lane & 31);
+      const bool qv = rq < R;
+      const int nn = qv ? rq / sh.K : 0, kk = qv ? rq % sh.K : 0;
+      const int64_t stat = ((int64_t)bh * sh.NQ + nn) * sh.K + kk;
+      g_ctx = qv ? min(a.ctx_len[kk], sh.S_text) : 0;    // 0 for rows past the end: masks everything
+      g_lse = qv ? a.lse[stat] : 0.f;
+      if constexpr (!OWN_DELTA) g_delta = qv ? a.delta[stat] : 0.f;
+      if constexpr (DROP) g_rkey = drop_row_key(drop, (uint32_t)rq);
+    }
   };
 
   // the gathered tile goes to this wave's staging area (row layout), with its rows' lse / ctx and delta
-  auto stage = [&]() __attribute__((always_inline)) {
+  auto stage_part = [&](auto part) __attribute__((always_inline)) {
+    constexpr int PART = decltype(part)::value;
 #pragma unroll
-    for (int i = 0; i < PERW; ++i) {
-      const int c = lane + i * 64;
+    for (int i = 0; i < PERG; ++i) {
+      const int c = lane + (PART * PERG + i) * 64;
       const int r = c / CPR, d0 = (c % CPR) * VEC;
       if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -364,11 +384,25 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
         if (c % CPR == 0) delta_s[r] = part;
       }
     }
-    if (lane < ATT_TILE) {
+    if (PART == 0 && lane < ATT_TILE) {
       lse_s[lane] = g_lse;
       if constexpr (!OWN_DELTA) delta_s[lane] = g_delta;
       ctx_s[lane] = g_ctx;
       if constexpr (DROP) rkey_s[lane] = g_rkey;
+    }
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  auto gather = [&](int tq) __attribute__((always_inline)) { gather_part(tq, P0()); };     // (one-part form: the whole tile)
+  auto stage = [&]() __attribute__((always_inline)) { stage_part(P0()); };
+  // gather + stage of a whole tile, one part after the other
+  auto fetch = [&](int tq) __attribute__((always_inline)) {
+    gather_part(tq, P0());
+    stage_part(P0());
+    if constexpr (GPARTS >= 2) { gather_part(tq, P1()); stage_part(P1()); }
+    if constexpr (GPARTS >= 4) {
+      gather_part(tq, std::integral_constant<int, 2>()); stage_part(std::integral_constant<int, 2>());
+      gather_part(tq, std::integral_constant<int, 3>()); stage_part(std::integral_constant<int, 3>());
     }
   };
 
@@ -393,6 +427,7 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       for (int o = 16; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
       if ((tid & 31) == 0 && rq / ATT_TILE < n_qtiles) reach_s[rq / ATT_TILE] = t;
     }
+    static_assert(GPARTS == 1, "the one-launch form keeps K / V in LDS: Dh <= 128");
     if (guess >= 0) gather(guess);
     gk.template store<true, false>(k_l, nullptr, tid);
     gv.template store<true, false>(v_l, nullptr, tid);
@@ -401,6 +436,38 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
     __syncthreads();
     kf.load(k_l + (lane & 31) * L::RSTRIDE);
     vf.load(v_l + (lane & 31) * L::RSTRIDE);
+  } else if constexpr (SL::PARK) {
+    // the K / V tile passes through wave 0's staging region on its way into every wave's registers (see BwdSplitLds::PARK);
+    // the bet's first gather flies meanwhile, and is staged once the region is free again
+    T* k_l = (T*)smem;
+    T* v_l = (T*)(smem + SL::TILE_BYTES);
+    TileRegs<T, DH, 256> gk, gv;
+    const int64_t base = (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh;
+    gk.load((const T*)a.k_text + base, sh.t_ss, key0, sh.S_text, tid);
+    gv.load((const T*)a.v_text + base, sh.t_ss, key0, sh.S_text, tid);
+    for (int r0 = 0; r0 < n_qtiles * ATT_TILE; r0 += 256) {
+      const int rq = r0 + tid;
+      int t = rq < R ? min(a.ctx_len[rq % sh.K], sh.S_text) : 0;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
+      if ((tid & 31) == 0 && rq / ATT_TILE < n_qtiles) reach_s[rq / ATT_TILE] = t;
+    }
+    if (guess >= 0) gather_part(guess, P0());
+    gk.template store<true, false>(k_l, nullptr, tid);
+    gv.template store<true, false>(v_l, nullptr, tid);
+    __syncthreads();
+    kf.load(k_l + (lane & 31) * L::RSTRIDE, true, h);
+    vf.load(v_l + (lane & 31) * L::RSTRIDE, true, h);
+    BG_TRACE(1, 1);
+    __syncthreads();
+    if (guess >= 0) {
+      stage_part(P0());
+      if constexpr (GPARTS >= 2) { gather_part(guess, P1()); stage_part(P1()); }
+      if constexpr (GPARTS >= 4) {
+        gather_part(guess, std::integral_constant<int, 2>()); stage_part(std::integral_constant<int, 2>());
+        gather_part(guess, std::integral_constant<int, 3>()); stage_part(std::integral_constant<int, 3>());
+      }
+    }
   } else {
     kf.load((const T*)a.k_text + row_off, kvalid, h);
     vf.load((const T*)a.v_text + row_off, kvalid, h);
@@ -411,7 +478,7 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       for (int o = 32; o > 0; o >>= 1) t = max(t, __shfl_xor(t, o));
       if (lane == 0) reach_s[tq] = t;
     }
-    if (guess >= 0) { gather(guess); stage(); }
+    if (guess >= 0) fetch(guess);
     BG_TRACE(1, 1);
     __syncthreads();
   }
@@ -454,9 +521,14 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
   while (tq >= 0) {
     ++my_tiles;
     if (!staged) {
-      if (!PREFETCH || !have) gather(tq);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
-      stage();
+      if constexpr (GPARTS == 1) {
+        if (!PREFETCH || !have) gather(tq);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's reads of the previous tile are done
+        stage();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        fetch(tq);
+      }
     }
     staged = false;
     have = false;
@@ -619,7 +691,12 @@ static int launch_split(const AttnArgs& a, bool one, hipStream_t st) {
   set_lds_limit(dqk, lq);
   hipLaunchKernelGGL(dqk, grid_q, dim3(256), lq, st, a);
   if (sh.S_text > 0) {
+    // Dh 256: ONE pass over the whole head dimension (round 3) instead of two half-passes that each recomputed S and dP and
+    // gathered Q / dO again; BRANCHGAN_ATTN_DKV256_HALVES=1 brings the two launches back (A/B runs)
+    static const bool halves = [] { const char* e = getenv("BRANCHGAN_ATTN_DKV256_HALVES"); return e && e[0] == '1'; }();
     if constexpr (DH <= 128) {
+      launch_dkv_split<T, DH, 0, DH / 32>(a, grid_k, reach, st);
+    } else if (!halves) {
       launch_dkv_split<T, DH, 0, DH / 32>(a, grid_k, reach, st);
     } else {
       launch_dkv_split<T, DH, 0, DH / 64>(a, grid_k, reach, st);
