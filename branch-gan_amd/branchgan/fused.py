@@ -589,6 +589,7 @@ BATCH_DW = os.environ.get("BRANCHGAN_BATCH_DW", "1") != "0"
 # it has flushed (or its autograd node is gone); a saved activation overwritten anyway (retain_graph + another forward) raises in
 # backward.  BRANCHGAN_STACKED_ACTIVATIONS=0: transient stacks, everything copied, as in the first step.
 STACKED_ACTIVATIONS = os.environ.get("BRANCHGAN_STACKED_ACTIVATIONS", "1") != "0"
+GELU_EPILOGUE = os.environ.get("BRANCHGAN_GELU_EPILOGUE", "1") != "0"      # no-grad passes: bias + tanh-GELU in the GEMM's epilogue
 STACK_BYTES_CAP = int(float(os.environ.get("BRANCHGAN_STACK_GIB", "48")) * (1 << 30))
 stack_stats = {"copied": 0, "in_place": 0}
 
@@ -938,6 +939,16 @@ class _Linear(torch.autograd.Function):
 def linear(x, weight, bias, layout, dtype, act=None, bias_grad=True, out_for=None):
     """bias_grad=False: the bias is added in forward but its gradient is somebody else's job (add_layer_norm(delta_bias=)).
     out_for (with act): the weight of the projection that reads the activation (see layer_norm)."""
+    if GELU_EPILOGUE and act == "gelu_tanh" and bias is not None and not torch.is_grad_enabled():
+        # Passes nobody differentiates (the sampling phase: root pass + branch steps; decoding): bias and tanh-GELU ride in the
+        # GEMM's epilogue (ONE hipBLASLt launch, the activation applied to the fp32 accumulator) - the pre-activation a backward
+        # pass would need is never written.  benchmarks/probes/addmm_gelu_probe.py: 11.1 -> 8.1 us at 256 rows, 25.1 -> 19.0 at 2048.
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != dtype:
+            x2 = x2.to(dtype)
+        w = lowp(weight, dtype)
+        y = torch._addmm_activation(lowp(bias, dtype), x2, w if layout == "io" else w.t(), use_gelu=True)
+        return y.view(*x.shape[:-1], y.shape[-1])
     track = None
     if STACKED_ACTIVATIONS and BATCH_DW and torch.is_grad_enabled() and weight.requires_grad:
         y_buf = None
