@@ -666,7 +666,11 @@ static int launch_split(const AttnArgs& a, bool one, hipStream_t st) {
   const int64_t R = (int64_t)sh.NQ * sh.K;
   const size_t reach = (size_t)cdiv(R, ATT_TILE) * 4 + 16;
   constexpr size_t lq = BwdSplitLds<T, DH, DH>::BYTES;
-  if constexpr (DH <= 128) {
+  // Dh 256 (bf16) CAN take the one-launch form since the full-width dK / dV pass (BRANCHGAN_ATTN_BWD_ONE256=1), but at one
+  // workgroup per CU (137 KB of LDS) the grid runs round after round whichever launch a workgroup belongs to: 155.2 us per
+  // call against 68.2 + 65.6 + 18.2 at configs[3] (profiles/r3_s_attn_c4_one256.txt) - off by default.
+  static const bool one256 = [] { const char* e = getenv("BRANCHGAN_ATTN_BWD_ONE256"); return e && e[0] == '1'; }();
+  if (DH <= 128 || one256) {
     if (one) {
       constexpr size_t lk = BwdSplitLds<T, DH, DH>::BYTES;
       size_t lds = lq > lk + reach ? lq : lk + reach;
