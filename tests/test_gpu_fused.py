@@ -370,6 +370,8 @@ def test_stacked_activations_written_in_place(monkeypatch):
     GELU forward; LayerNorm, attention, GELU backward) write them in place: nothing is copied any more, and the gradients are
     bit-identical to the all-copied form.  Root pass + tree pass share the weights (two passes per stack)."""
     from branchgan import fused, models, training
+    if not fused.BATCH_DW:
+        pytest.skip("batched weight-gradient GEMMs are switched off (A/B run)")
     model = _gpt2(hidden=128, heads=4, layers=3)
     B, S, K = 2, 40, 4
     g = torch.Generator(device="cuda").manual_seed(5)

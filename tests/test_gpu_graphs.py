@@ -88,7 +88,9 @@ def test_graph_replays_match_eager_at_c2_shapes(amp, fused_on, monkeypatch):
     gs = GraphedTrainStep(model, conf, g_opt, d_opt, data[0], 9999, rl, amp, warmup=1)
     nodes, kernels, memsets, _ = map(sum, zip(*gs.census))
     assert kernels > 500
-    assert gs._side_by_side == fused_on      # the two backward graphs beside each other: only on the path whose scratch this library owns
+    import os
+    if os.environ.get("BRANCHGAN_OVERLAP_BWD") != "0":       # (an A/B run may switch the overlap off)
+        assert gs._side_by_side == fused_on  # the two backward graphs beside each other: only on the path whose scratch this library owns
     if not fused_on:
         assert memsets > 0                   # ATen's multi-block reductions brought memset nodes; all were replaced
     worst = 0.0
