@@ -28,7 +28,8 @@ class AttnShape(ctypes.Structure):
                 ("t_sb", c_i64), ("t_sh", c_i64), ("t_ss", c_i64),
                 ("s_sb", c_i64), ("s_sh", c_i64), ("s_sk", c_i64),
                 ("dq_sb", c_i64), ("dq_sh", c_i64), ("dq_sn", c_i64), ("dq_sk", c_i64),
-                ("p_drop", c_f32), ("drop_call", ctypes.c_uint32), ("drop_state", c_vp)]
+                ("p_drop", c_f32), ("drop_call", ctypes.c_uint32), ("drop_state", c_vp),
+                ("drop_row0", ctypes.c_uint32), ("drop_reserved", ctypes.c_uint32)]
 
 
 class DiscLossShape(ctypes.Structure):
@@ -76,6 +77,7 @@ SIGNATURES = {
     "bg_branch_attn_weights": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "bg_attn_dropout_mask": (c_i32, [ctypes.POINTER(AttnShape), c_vp, c_vp]),
     "bg_dropout_advance": (c_i32, [c_vp, c_vp]),
+    "bg_dropout_rows": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i32, ctypes.c_uint32, c_f32, ctypes.c_uint32, c_vp, c_vp]),
     "bg_neox_qkv_rope_fwd": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "bg_neox_qkv_rope_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "bg_add_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),

@@ -999,7 +999,8 @@ class _MergedTreeAttention(torch.autograd.Function):
         lse_t = torch.empty((B, H, N, K), dtype=torch.float32, device=qkv.device)
         kview, vview = qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
         kt, vt = kview[:, :, :S], vview[:, :, :S]
-        drops = (ops.drop_descriptor(spec.get("p_drop")), ops.drop_descriptor(spec.get("p_drop")))     # root rows, tree rows
+        drops = (ops.drop_descriptor(spec.get("p_drop"), spec.get("drop_site"), 0),                  # root rows, tree rows
+                 ops.drop_descriptor(spec.get("p_drop"), spec.get("drop_site"), spec.get("drop_row0", 0)))
         _attn_fwd_call(_heads_first(qkv[:, :S, 0], 1, S), kt, vt, [], [], ops.causal_ctx_len(S, S, qkv.device), [[]], spec["scale"],
                        _heads_first(att[:, :S], 1, S), lse_r, drops[0])
         own = lambda t: [t[:, :, S + n * K:S + (n + 1) * K] for n in range(N)]
@@ -1075,7 +1076,7 @@ class _PackedAttention(torch.autograd.Function):
                 raise NotImplementedError("ancestor KV slots must share the packed-QKV layout of the new tokens")
             slots_k, slots_v = anc_k + own_k, anc_v + own_v
         path, path_len, max_path = ops.path_tables(paths, qkv.device)
-        drop = ops.drop_descriptor(spec.get("p_drop"))
+        drop = ops.drop_descriptor(spec.get("p_drop"), spec.get("drop_site"), 0 if root else spec.get("drop_row0", 0))
         sh = ops._attn_shape(q5, kt, slots_k, spec["scale"], max_path, o5, drop)
         ops.attn_fwd_launch(sh, q5, kt, vt, slots_k, slots_v, ctx_len, path, path_len, o5, lse)
         ctx.save_for_backward(qkv, att, lse, ctx_len, path, path_len, *([] if root else [kt, vt]), *anc_k, *anc_v)
@@ -1156,13 +1157,14 @@ def _dqkv_buffer(qkv, qkv_from):
     return t.view(qkv.shape) if t is not None else torch.empty_like(qkv)
 
 
-def packed_attention(qkv, lp, scale, out_for=None, qkv_from=None, p_drop=0.0):
+def packed_attention(qkv, lp, scale, out_for=None, qkv_from=None, p_drop=0.0, drop_site=None, drop_row0=0):
     """qkv (B,T,3,H,Dh).  lp: None (root causal) or the layer view of a BranchPast.  -> (att (B,T,E), (k, v) views).
     out_for: the weight of the projection that reads att; qkv_from: the weight of the projection that produced qkv (see layer_norm /
-    add_layer_norm)."""
+    add_layer_norm).  drop_site / drop_row0: the dropout masks as functions of (site, logical row) - text rows 0.., tree rows
+    from drop_row0 - instead of the call order (ops.drop_site)."""
     B, T, _, H, Dh = qkv.shape
     extra = {"att_buf": _x_slab_for(out_for, B * T, H * Dh, qkv.dtype, qkv.device), "qkv_from": _pass_of(qkv_from, qkv.device),
-             "p_drop": p_drop}
+             "p_drop": p_drop, "drop_site": drop_site, "drop_row0": drop_row0}
     if lp is None:
         att, k, v = _PackedAttention.apply(qkv, None, None, {"scale": float(scale), **extra})
     elif getattr(lp, "merged_text", 0):

@@ -30,7 +30,9 @@ _IGNORED_BUFFERS = (".attention.bias", ".attention.self_bias", ".attention.maske
 class BranchPast:
     """KV context + arithmetic mask of one branch forward over NQ query nodes x K branch points."""
 
-    def __init__(self, text, ancestors, ctx_len, paths, n_query_nodes=1, merged_text=0):
+    def __init__(self, text, ancestors, ctx_len, paths, n_query_nodes=1, merged_text=0, node_uid0=0):
+        self.node_uid0 = node_uid0          # number of the first query node among the tree's forwarded nodes (dropout sites: a
+        #                                     branch step over node i and the tree pass over all nodes draw the same masks for it)
         self.merged_text = merged_text      # > 0: the first merged_text input tokens ARE the text (one pass over text + tree)
         self.text = text                    # per layer (k_text, v_text)  (B,H,S,Dh); None in merged form
         self.ancestors = ancestors          # per layer list of (k, v) slots (B,H,K,Dh), possibly empty
@@ -130,6 +132,18 @@ def dropout_active(model, dropoutRate=None):
     if lm._fused_family == "gpt2":
         return bool(dropoutRate or cfg.attn_pdrop or cfg.embd_pdrop or cfg.resid_pdrop)
     return bool(lm.training and (cfg.attn_pdrop or cfg.resid_pdrop))
+
+
+def dropout_by_site(model):
+    """Are the dropout masks of `model`'s forwards functions of (step, site, logical row) alone - the same whether a tree node
+    is forwarded alone (a branch step) or with every other node (the tree pass)?  True for the GPT-2 family on the fused path
+    (ops.drop_site / ops.dropout_rows); the module-by-module path and the NeoX blocks draw theirs in call order / from torch's
+    generator."""
+    lm = next((m for m in model.modules() if isinstance(m, _LMBase) and hasattr(m, "_fused_family")), None)
+    if lm is None or lm._fused_family != "gpt2" or not fused.ENABLED:
+        return False
+    p0 = next(lm.parameters())
+    return p0.is_cuda and p0.dtype == torch.float32 and fused.supported_width(lm.config.hidden_size) and lm.config.head_dim in (32, 64, 128)
 
 
 _rope_cache = {}
@@ -594,15 +608,18 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
-    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None, dropoutRate=None):
+    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None, dropoutRate=None, drop_ctx=None):
         """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
         block's MLP output - of the projection with weight delta_from -, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel.
         -> (x2, m, bias of m's projection or None, present, weight of m's projection or None): the last two are None when a
         dropout sits between that projection and the residual add (the LayerNorm backward's shortcuts then do not apply).
         Dropouts as in the reference: attention probabilities (inside the attention kernels) and attention output always on
-        at dropoutRate or the config's rates, the MLP's nn.Dropout in training mode only."""
+        at dropoutRate or the config's rates, the MLP's nn.Dropout in training mode only.  Their masks are functions of (step,
+        site, logical row): drop_ctx = (model salt, text rows of this pass, logical number of its first tree row), ops.drop_site."""
         at = self.attn
         B, T, _ = x.shape
+        salt, text_rows, row0 = drop_ctx if drop_ctx is not None else (0, T, 0)
+        site = lambda kind: ops.drop_site(salt, at.layer_idx or 0, kind)
         # out_for / delta_from / qkv_from name the projection on the other side of a tensor: producers then write the stacked
         # operands of the batched weight-gradient GEMMs in place (fused._DeferredWeightGrads)
         if delta is None:
@@ -611,18 +628,19 @@ class NonResidualGPT2Block(nn.Module):
             x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias, out_for=at.c_attn.weight, delta_from=delta_from)
         qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
         a, present = fused.packed_attention(qkv, lp, at._scale(), out_for=at.c_proj.weight, qkv_from=at.c_attn.weight,
-                                            p_drop=at._p_attn(dropoutRate))
+                                            p_drop=at._p_attn(dropoutRate), drop_site=site(ops.SITE_ATTN), drop_row0=row0)
         # the two projections that feed a residual add leave their bias gradient to the LayerNorm backward that follows
         p_res = at._p_resid(dropoutRate)
         if p_res:
-            a = F.dropout(fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype), p_res, True)
+            a = ops.dropout_rows(fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype), p_res, site(ops.SITE_RESID), row0, text_rows)
             x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, out_for=self.mlp.c_fc.weight)
         else:
             a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
             x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight)
         g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh", out_for=self.mlp.c_proj.weight)
         if self.mlp.resid_pdrop and self.training:
-            delta = F.dropout(fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), self.mlp.resid_pdrop, True)
+            delta = ops.dropout_rows(fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), self.mlp.resid_pdrop,
+                                     site(ops.SITE_MLP), row0, text_rows)
             return x2, delta, None, present, None
         delta = fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype, bias_grad=False)
         return x2, delta, self.mlp.c_proj.bias, present, self.mlp.c_proj.weight
@@ -649,6 +667,7 @@ class NonResidualGPT2LMHeadModel(_LMBase):
         self.transformer = NonResidualGPT2Model(config)
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
         self.valueHead = nn.Linear(config.hidden_size, 1, bias=False)
+        self._drop_salt = 0                 # tells the models of a step apart in their dropout sites (the wrappers set 1 / 2)
         self._init_weights(config.initializer_range)
 
     def forward(self, input_ids=None, past_key_values=None, attention_mask=None, token_type_ids=None, position_ids=None,
@@ -663,19 +682,26 @@ class NonResidualGPT2LMHeadModel(_LMBase):
         pos = _positions(position_ids, B, T, input_ids.device)
         branch = textualPast is not None
         tr = self.transformer
+        merged_text = getattr(textualPast, "merged_text", 0) if branch else 0
+        if not branch or merged_text:
+            ops.dropout_new_pass()          # a forward over a text: fresh dropout sites for it and the tree passes that hang off it
         if _fused_eligible(self, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate):
             dtype = fused.compute_dtype(tr.wte.weight)
             fused.prepare_weights(self, dtype)
+            # logical rows of this pass for the dropout masks: text positions as they are, tree rows from their node's number
+            text_rows = merged_text if branch else T
+            row0 = ops.TREE_ROW_BASE + getattr(textualPast, "node_uid0", 0) * int(textualPast.ctx_len.numel()) if branch else 0
+            drop_ctx = (self._drop_salt, text_rows, row0)
             with torch.autocast("cuda", enabled=False):
                 x, delta, delta_bias, presents = fused.embedding(input_ids, pos, tr.wte.weight, tr.wpe.weight), None, None, []
                 p_emb = dropoutRate if dropoutRate is not None else self.config.embd_pdrop
                 if p_emb:                                           # always on (NonResidualDiscriminatorBase.py:231-232)
-                    x = F.dropout(x, p_emb, True)
+                    x = ops.dropout_rows(x, p_emb, ops.drop_site(self._drop_salt, 0x1FF, ops.SITE_EMBED), row0, text_rows)
                 delta_from = None
                 for i, block in enumerate(tr.h):
                     x, delta, delta_bias, present, delta_from = block.fused_forward(x, delta, delta_bias, dtype,
                                                                                     _layer_past(textualPast, i) if branch else None, delta_from,
-                                                                                    dropoutRate)
+                                                                                    dropoutRate, drop_ctx)
                     presents.append(present)
                 _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias, delta_from=delta_from)
                 head = self.lm_head if returnLmLogits else self.valueHead
@@ -735,6 +761,7 @@ class NonResidualGenerator(nn.Module):
         super().__init__()
         self.config = LMConfig.from_any(generatorConfig)
         self.generator = make_lm(self.config)
+        self.generator._drop_salt = 1
 
     def forward(self, args):
         args = dict(args)
@@ -755,6 +782,7 @@ class NonResidualDiscriminatorWithDualValueHeads(nn.Module):
         super().__init__()
         self.discriminatorConfig = LMConfig.from_any(discriminatorConfig)
         self.nonResidualModel = make_lm(self.discriminatorConfig)
+        self.nonResidualModel._drop_salt = 2
         self.inputValueHead = nn.Linear(self.discriminatorConfig.hidden_size, 1)
         self.alterationsValueHead = nn.Linear(self.discriminatorConfig.hidden_size, 1)
         self.hasValueHeads = True

@@ -215,9 +215,38 @@ def _ptr_array(tensors):
 
 # Dropout on the attention probabilities (csrc/attn_dropout.h).  One (seed, step counter) pair per device, in device memory: the
 # kernels read it when they run, so a captured step draws fresh masks on every replay once dropout_advance() is part of it.
-# A `drop` descriptor is (p, call): call tells the attention calls of one step apart and is the same in forward and backward.
+# A `drop` descriptor is (p, call, row0): call tells the attention calls of one step apart and is the same in forward and
+# backward; row0 is added to the call's query rows before they enter the mask function.
+#
+# Two ways of numbering calls.  Call ORDER (drop_descriptor(p)): the n-th call of a step, top bit set - whoever calls the attention
+# functions directly.  SITES (drop_site): (pass, model, layer, kind) - the models' fused path.  A site does not depend on how the
+# step is scheduled: a no-grad branch step over ONE tree node and the later differentiated pass over ALL nodes name the same site
+# and line their rows up through row0 (tree rows start at TREE_ROW_BASE + uid * K), so they draw the SAME masks - which is what
+# lets the sampling phase run without autograd under dropout (tree.multiStepGenForward).  The pass number moves on with every
+# forward over a text (dropout_new_pass), so two micro-batches inside one step do not share masks either.
 _drop_states = {}
 _drop_calls = itertools.count(1)
+_drop_pass = 0
+TREE_ROW_BASE = 1 << 20
+SITE_ATTN, SITE_RESID, SITE_MLP, SITE_EMBED = 0, 1, 2, 3
+_model_salts = itertools.count(1)
+
+
+def new_model_salt():
+    """A small number that tells the models of a process apart in their dropout sites (generator vs discriminator)."""
+    return next(_model_salts) & 0xFF
+
+
+def dropout_new_pass():
+    """A new forward pass over a text begins: its dropout sites (and those of the branch steps / tree passes hanging off it)
+    get a fresh pass number.  Host-side: a captured graph keeps the numbers it was recorded with, the device counter moves."""
+    global _drop_pass
+    _drop_pass += 1
+
+
+def drop_site(salt, layer, kind):
+    """32-bit site word (top bit clear): pass 11 bits | model 8 | layer 9 | kind 3."""
+    return ((_drop_pass & 0x7FF) << 20) | ((salt & 0xFF) << 12) | ((layer & 0x1FF) << 3) | (kind & 7)
 
 
 def dropout_state(device):
@@ -242,18 +271,54 @@ def dropout_advance(device="cuda"):
     """step counter += 1 on the current stream (bg_dropout_advance): once per train step, inside the captured region.  The
     call numbers restart with it: the n-th attention call of a step has number n whether the step runs eagerly or is being
     captured (a captured step and an eager one on the same (seed, counter) then draw the same masks)."""
-    global _drop_calls
+    global _drop_calls, _drop_pass
     C.check(C.lib().bg_dropout_advance(C.ptr(dropout_state(device)), C.stream_ptr()), "bg_dropout_advance")
     _drop_calls = itertools.count(1)
+    _drop_pass = 0
 
 
-def drop_descriptor(p):
-    """(p, fresh call number) for one attention call, or None when p is 0 / None."""
+def drop_descriptor(p, site=None, row0=0):
+    """(p, call word, row0) for one attention call, or None when p is 0 / None.  site None: a fresh call number (call order)."""
     if not p:
         return None
     if not 0.0 < float(p) < 1.0:
         raise ValueError(f"attention dropout rate {p} is not in [0, 1)")
-    return (float(p), next(_drop_calls) & 0xFFFFFFFF)
+    call = (0x80000000 | (next(_drop_calls) & 0x7FFFFFFF)) if site is None else (int(site) & 0x7FFFFFFF)
+    return (float(p), call, int(row0) & 0xFFFFFFFF)
+
+
+class _DropoutRows(torch.autograd.Function):
+    """bg_dropout_rows: x (B, T, C) -> x * keep / (1 - p); backward = the same call on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, site, row0, text_rows):
+        ctx.meta = (p, site, row0, text_rows)
+        return _dropout_rows_call(x, p, site, row0, text_rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, site, row0, text_rows = ctx.meta
+        return _dropout_rows_call(dy, p, site, row0, text_rows), None, None, None, None
+
+
+def _dropout_rows_call(x, p, site, row0, text_rows):
+    B, T, Cc = x.shape
+    if x.stride(-1) != 1 or x.stride(0) != T * x.stride(1) or x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
+    y = torch.empty((B, T, Cc), dtype=x.dtype, device=x.device)
+    C.check(C.lib().bg_dropout_rows(C.ptr(x), C.ptr(y), C.dtype_code(x), B, T, Cc, x.stride(1), Cc, int(text_rows), int(row0) & 0xFFFFFFFF,
+                                    float(p), int(site) & 0x7FFFFFFF, C.ptr(dropout_state(x.device)), C.stream_ptr()), "bg_dropout_rows")
+    return y
+
+
+def dropout_rows(x, p, site, row0=0, text_rows=None):
+    """Dropout over a (B, T, C) activation with the counter-based generator of the attention dropout (bg_dropout_rows): the
+    first `text_rows` rows (default: all) are text positions, the rest are tree rows whose logical number starts at row0."""
+    if not p:
+        return x
+    if not 0.0 < float(p) < 1.0:
+        raise ValueError(f"dropout rate {p} is not in [0, 1)")
+    return _DropoutRows.apply(x, float(p), int(site), int(row0), x.shape[1] if text_rows is None else int(text_rows))
 
 
 def attn_dropout_mask(sh_like, device):
@@ -277,7 +342,8 @@ def _attn_shape(q, k_text, slots_k, scale, max_path, out, drop=None):
     if slots_k:
         sh.s_sb, sh.s_sh, sh.s_sk = slots_k[0].stride()[:3]
     if drop is not None:
-        sh.p_drop, sh.drop_call = drop
+        sh.p_drop, sh.drop_call = drop[0], drop[1]
+        sh.drop_row0 = drop[2] if len(drop) > 2 else 0
         sh.drop_state = dropout_state(q.device).data_ptr()
     return sh
 

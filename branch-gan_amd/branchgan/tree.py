@@ -11,6 +11,7 @@ node fields callers read.  What changed underneath (all exactness-preserving, SU
     reference, :357-362): query (node, k) sees text[0..s_k], its ancestors' column k and itself.
 """
 import contextlib
+import os
 import weakref
 
 import torch
@@ -249,10 +250,12 @@ def _clean(params):
     return {k: v for k, v in params.items() if k not in ('includeFinalTimeStep', 'blockSamplingOfLabels', 'dropoutRate')}
 
 
-def _branch_step(generator, node, device, dropoutRate, numAlterations, strat, params, noise_fn, ids=None):
+def _branch_step(generator, node, device, dropoutRate, numAlterations, strat, params, noise_fn, ids=None, uid=0):
     """One generator forward over a branch node and the sampling of its children: -> (log probs (B,K,n), past, ids (B,n,K)).
-    With `ids` given nothing is sampled: the log probs of those ids are returned (re-forward with autograd)."""
+    With `ids` given nothing is sampled: the log probs of those ids are returned (re-forward with autograd).
+    uid: the node's number among the tree's forwarded nodes (its rows in the tree pass: dropout masks line up through it)."""
     predIDs, positionalIDs, past, _ = node.producePredictionStep(device)
+    past.node_uid0 = uid
     output = generator.forward({'input_ids': predIDs, 'position_ids': positionalIDs, 'textualPast': past,
                                 'returnLmLogits': True, 'use_cache': True, 'dropoutRate': dropoutRate})
     step_logits = output.prediction.logits                                                # (B, K, V)
@@ -270,6 +273,8 @@ def _set_child_log_probs(node, lp):
 
 
 _row_map_cache = {}
+# A/B: sample without autograd and differentiate in one tree pass also when the generator draws dropout masks (by site)
+DEFER_UNDER_DROPOUT = os.environ.get("BRANCHGAN_DEFER_UNDER_DROPOUT", "1") != "0"
 
 
 def _node_rows(B, N, K, i, device):
@@ -291,9 +296,9 @@ def _attach_branch_gradients(generator, root, forwarded, device, pending=(), noi
     N = len(forwarded)
     if N > ops.MAX_SLOTS:
         assert not pending
-        for node in forwarded:
+        for i, node in enumerate(forwarded):
             ids = torch.stack([c.ids for c in node.children], dim=1)
-            lp, past, _ = _branch_step(generator, node, device, None, ids.shape[1], None, None, None, ids=ids)
+            lp, past, _ = _branch_step(generator, node, device, None, ids.shape[1], None, None, None, ids=ids, uid=i)
             node.past = past
             _set_child_log_probs(node, lp)
         return
@@ -371,9 +376,12 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
     # Sampling is sequential by depth, differentiation is not: the branch forwards below run WITHOUT autograd (they only have
     # to produce ids), then ONE pass over every forwarded node (the same tree attention the discriminator uses) rebuilds their
     # logits with autograd, so the backward is one pass over N*K tokens instead of one per node.  Same mathematics as the
-    # reference's per-node graph (MultiStepPrediction.py:296-327); dropout would draw different masks, so it keeps the old way.
+    # reference's per-node graph (MultiStepPrediction.py:296-327).  Under dropout the two passes must draw the SAME masks for a
+    # node's rows: true where the masks are functions of (step, site, logical row) (models.dropout_by_site: the GPT-2 family on
+    # the fused path, at the config's rates); per-rule rates, the module path and NeoX's nn.Dropout keep the per-node graph.
     track = torch.is_grad_enabled() and logits.requires_grad
-    deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules) and not models.dropout_active(generator)
+    deferred = track and not any(r.samplingParams.get('dropoutRate') for r in sampleRules) and \
+        (not models.dropout_active(generator) or (DEFER_UNDER_DROPOUT and models.dropout_by_site(generator)))
     forwarded, pending = [], []
     rules = sampleRules[1:]
     for r_i, rule in enumerate(rules):
@@ -390,14 +398,14 @@ def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=
                 continue
             with torch.no_grad() if deferred else contextlib.nullcontext():
                 lp, past, altIDs = _branch_step(generator, node, device, rule.samplingParams.get('dropoutRate', None),
-                                                numAlterations, strat, params, noise_fn)
+                                                numAlterations, strat, params, noise_fn, uid=len(forwarded))
             node.addGeneratorPredictionToNode(altIDs, past, None, None, getRandomNodesFromRule(strat, params, numAlterations),
                                               logProbs=lp)
             forwarded.append(node)
     if pending and len(forwarded) + len(pending) > ops.MAX_SLOTS:          # too many nodes for one pass: a branch step each
         for node, strat, params, numAlterations in pending:
             with torch.no_grad():
-                lp, past, altIDs = _branch_step(generator, node, device, None, numAlterations, strat, params, noise_fn)
+                lp, past, altIDs = _branch_step(generator, node, device, None, numAlterations, strat, params, noise_fn, uid=len(forwarded))
             node.addGeneratorPredictionToNode(altIDs, past, None, None, getRandomNodesFromRule(strat, params, numAlterations),
                                               logProbs=lp)
             forwarded.append(node)

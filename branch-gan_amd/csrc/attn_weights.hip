@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void branch_attn_weights_kernel(AttnArgs a, fl
   const float lse = a.lse[(((int64_t)b * sh.H + h) * sh.NQ + n) * sh.K + k];
   // with dropout the reference hands out the weights AFTER the dropout (kept ones scaled by 1 / (1 - p)): the same mask here
   const bool dropping = sh.p_drop > 0.f;
-  DropKeys drop = {0u, 0u, 0u, 1.f};
+  DropKeys drop = {0u, 0u, 0u, 0u, 1.f};
   uint32_t row_key = 0;
   if (dropping) {
     drop = drop_keys(a, b * sh.H + h);

@@ -174,10 +174,15 @@ typedef struct {
    * (drop_state[0] = seed, drop_state[1] = step counter, drop_call, batch*head, query row n*K + k, key column), regenerated by
    * the backward call that passes the same p_drop / drop_call / drop_state contents (bg_attn_dropout_mask writes it out).
    * drop_state is DEVICE memory read when the kernel runs: advance the counter (bg_dropout_advance) between the replays of
-   * a captured graph to draw fresh masks; drop_call tells the attention calls of one step apart.  Dh <= 128 only. */
+   * a captured graph to draw fresh masks; drop_call tells the attention calls of one step apart.  Dh <= 128 only.
+   * drop_row0 is added to the query row before it enters the function: two calls that cover the same logical rows at different
+   * positions (a branch step over ONE tree node, later a tree pass over all nodes) draw the same mask for them when they pass the
+   * same drop_call and the row offsets that line the rows up. */
   float p_drop;
   uint32_t drop_call;
   const uint64_t* drop_state;
+  uint32_t drop_row0;
+  uint32_t drop_reserved;             /* 0 */
 } bg_attn_shape;
 
 int bg_branch_attn_fwd(const bg_attn_shape* shape,
@@ -231,6 +236,17 @@ int bg_attn_dropout_mask(const bg_attn_shape* shape, uint8_t* keep, void* stream
 
 /* drop_state[1] += 1 on the stream (one thread): the step counter of the dropout masks, see bg_attn_shape. */
 int bg_dropout_advance(uint64_t* drop_state, void* stream);
+
+/* Dropout over the rows of an activation, out = in * keep / (1 - p), with the mask of the attention dropout's generator instead
+ * of torch's (GPT-2: F.dropout on the attention block's output NonResidualAttention.py:274-275 and on the embeddings
+ * NonResidualDiscriminatorBase.py:231-232, always on; nn.Dropout of GPT2MLP / NeoXNonResidualBase.py:79-80,110-125 in training
+ * mode): the keep decision of element (b, t, c) of a [batch][rows][cols] activation is a function of (drop_state, site, b,
+ * logical row, c), logical row = t for t < text_rows, else row0 + (t - text_rows) - so a no-grad branch step over one tree node
+ * and the later differentiated pass over all nodes draw the same mask for the same token (what lets the sampling phase run
+ * without autograd under dropout), and the backward pass is the same call on the gradient.  in == out is allowed.
+ * dtype BG_F32 / BG_BF16; row_stride in elements (cols contiguous); batch < 4096, logical rows < 2^20. */
+int bg_dropout_rows(const void* in, void* out, int dtype, int batch, int rows, int cols, int64_t in_row_stride, int64_t out_row_stride,
+                    int text_rows, uint32_t row0, float p, uint32_t site, const uint64_t* drop_state, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NeoX prologue: split the fused QKV projection, move heads forward and apply partial rotary.

@@ -285,3 +285,111 @@ def test_captured_step_with_attention_dropout_draws_fresh_masks_and_matches_eage
             err = float((a - b).abs().max()) / float(b.abs().max())
             assert err <= 1e-5, f"replay {r} {name} arena: {err:.3e}"
         g_opt.arena.zero(); d_opt.arena.zero()
+
+
+@pytest.mark.parametrize("dtype,cols", [(torch.float32, 768), (torch.bfloat16, 768), (torch.bfloat16, 100), (torch.float32, 37)])
+def test_dropout_rows_is_a_function_of_site_and_logical_row(dtype, cols):
+    """bg_dropout_rows: keep rate and scaling; the decision of a token depends on (seed, step, site, batch, LOGICAL row, column)
+    only - a call over one tree node's rows (row0 = base + i K) reproduces rows [i K, (i + 1) K) of the call over all nodes,
+    text rows keep their own numbers in a merged call - and the backward pass applies the forward's mask to the gradient."""
+    from branchgan import ops
+    B, S, N, K, p = 3, 20, 4, 8, 0.25
+    ops.seed_dropout(11)
+    site = ops.drop_site(1, 5, ops.SITE_RESID)
+    x = (torch.rand(B, S + N * K, cols, device="cuda") + 0.5).to(dtype)
+    base = ops.TREE_ROW_BASE
+    full = ops.dropout_rows(x, p, site, base, S)                           # merged: S text rows, then N nodes of K rows
+    kept = full != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    torch.testing.assert_close(full[kept].float(), (x[kept].float() / (1 - p)).to(dtype).float(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=0)
+    text = ops.dropout_rows(x[:, :S].contiguous(), p, site, 0, S)          # the text alone
+    assert torch.equal(text, full[:, :S])
+    tree = ops.dropout_rows(x[:, S:].contiguous(), p, site, base, 0)       # the tree alone
+    assert torch.equal(tree, full[:, S:])
+    for i in range(N):                                                     # one node alone (a branch step)
+        rows = slice(S + i * K, S + (i + 1) * K)
+        one = ops.dropout_rows(x[:, rows].contiguous(), p, site, base + i * K, 0)
+        assert torch.equal(one, full[:, rows]), i
+    other_site = ops.dropout_rows(x, p, ops.drop_site(1, 6, ops.SITE_RESID), base, S)
+    assert not torch.equal(other_site != 0, kept)
+    per_batch = kept[:, :, : min(cols, 32)].flatten(1).float()
+    assert not torch.equal(per_batch[0], per_batch[1])                     # batch rows draw their own
+    ops.dropout_advance("cuda")
+    assert not torch.equal(ops.dropout_rows(x, p, site, base, S) != 0, kept)     # next step: another draw
+    ops.seed_dropout(11)
+    xr = x.float().requires_grad_(True)
+    y = ops.dropout_rows(xr, p, site, base, S)
+    g = torch.randn_like(y)
+    y.backward(g)
+    torch.testing.assert_close(xr.grad, g * (y.detach() != 0).float() / (1 - p))
+
+
+def test_attention_dropout_rows_line_up_between_branch_step_and_tree_pass():
+    """The attention-probability mask of a call over ONE tree node with drop_row0 = base + i K equals rows [i K, (i + 1) K) of
+    the mask of the call over all nodes (drop_row0 = base) at the same site."""
+    from branchgan import ops
+    B, H, N, K, S, Dh = 2, 3, 3, 16, 40, 32
+    ops.seed_dropout(3)
+    site = ops.drop_site(1, 2, ops.SITE_ATTN)
+    q_all = torch.zeros(B, H, N, K, Dh, device="cuda")
+    kt = torch.zeros(B, H, S, Dh, device="cuda")
+    slots = [torch.zeros(B, H, K, Dh, device="cuda") for _ in range(N)]
+    full = _mask_of(ops, q_all, kt, slots, 3, ops.drop_descriptor(0.3, site, ops.TREE_ROW_BASE), 1.0)        # (B,H,N*K,S+3)
+    for i in range(N):
+        one = _mask_of(ops, q_all[:, :, :1], kt, slots, 3, ops.drop_descriptor(0.3, site, ops.TREE_ROW_BASE + i * K), 1.0)
+        assert torch.equal(one, full[:, :, i * K:(i + 1) * K]), i
+    assert abs(float(full.float().mean()) - 0.7) < 0.02
+
+
+def test_generator_forward_under_dropout_samples_without_autograd_and_matches_the_per_node_graph(monkeypatch):
+    """GPT-2 generator with the stock dropout rates: the sampling phase runs without autograd and ONE tree pass rebuilds the
+    nodes' logits (as without dropout), because the masks are functions of (step, site, logical row).  Against the per-node
+    autograd graph (the reference's schedule) on the same (seed, step): the same sampled ids at every node, the same log
+    probabilities and the same parameter gradients to fp32 kernel tolerance."""
+    import dataclasses
+    from branchgan import configs, models, ops, sampling, tree
+    torch.manual_seed(0)
+    cfg = dataclasses.replace(configs.LMConfig.from_any("gpt2-tiny"), attn_pdrop=0.1, resid_pdrop=0.1, embd_pdrop=0.1)
+    gen = models.NonResidualGenerator(cfg).cuda()
+    gen.train()
+    assert models.dropout_active(gen) and models.dropout_by_site(gen)
+    ids = torch.randint(0, cfg.vocab_size, (3, 48), generator=torch.Generator().manual_seed(2)).cuda()
+    sparse = torch.tensor([1, 5, 9, 14, 20, 27, 33, 40], device="cuda")
+    noise = lambda shape, device: torch.rand(shape, generator=torch.Generator().manual_seed(9)).to(device)
+
+    tree_passes = []
+    attach = tree._attach_branch_gradients
+    monkeypatch.setattr(tree, "_attach_branch_gradients", lambda *a, **k: (tree_passes.append(1), attach(*a, **k))[1])
+
+    def run(defer):
+        monkeypatch.setattr(tree, "DEFER_UNDER_DROPOUT", defer)
+        rules = [sampling.SamplingRule(2, sampling.SamplingTechniques.TOP_K, {}), sampling.SamplingRule(1, sampling.SamplingTechniques.TOP_K, {}),
+                 sampling.SamplingRule(1, sampling.SamplingTechniques.SAMPLE_NO_REPLACEMENT, {})]
+        ops.seed_dropout(21)
+        ops.dropout_advance("cuda")
+        gen.zero_grad()
+        root, *_ = tree.multiStepGenForward(gen, ids, rules, "cuda", clearTreePast=False, sparseIndex=sparse, noise_fn=noise)
+        nodes = [n for n in root.getSubNodes() if n.depth > 0]
+        loss = sum(n.logProbs.sum() for n in nodes) + root.labelLogProbs.sum()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
+        return [n.ids.clone() for n in nodes], [n.logProbs.detach().clone() for n in nodes], grads, float(loss)
+
+    ids_d, lp_d, g_d, loss_d = run(True)
+    assert len(tree_passes) == 1                      # sampled without autograd, differentiated in one tree pass
+    ids_n, lp_n, g_n, loss_n = run(False)
+    assert len(tree_passes) == 1                      # the per-node graph: no tree pass
+    assert len(ids_d) == len(ids_n) == 2 + 2 + 2
+    for a, b in zip(ids_d, ids_n):
+        assert torch.equal(a, b)
+    for a, b in zip(lp_d, lp_n):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
+    assert abs(loss_d - loss_n) <= 2e-4 * abs(loss_n)
+    for k in g_n:
+        err = float((g_d[k] - g_n[k]).abs().max()) / (float(g_n[k].abs().max()) + 1e-12)
+        assert err < 2e-3, (k, err)
+    # and the masks ARE in play: another step draws other masks, other numbers
+    monkeypatch.setattr(tree, "DEFER_UNDER_DROPOUT", True)
+    ops.seed_dropout(22)
+    root, *_ = tree.multiStepGenForward(gen, ids, [sampling.SamplingRule(2, sampling.SamplingTechniques.TOP_K, {})], "cuda", sparseIndex=sparse)
+    assert abs(float(root.labelLogProbs.sum()) - float(sum(0 for _ in ()))) > 0 and not torch.allclose(root.children[0].logProbs.detach(), lp_d[0])
