@@ -32,6 +32,11 @@ class AttnShape(ctypes.Structure):
                 ("drop_row0", ctypes.c_uint32), ("drop_reserved", ctypes.c_uint32)]
 
 
+class RowDropout(ctypes.Structure):
+    _fields_ = [("p", c_f32), ("site", ctypes.c_uint32), ("row0", ctypes.c_uint32), ("text_rows", c_i32), ("rows_per_batch", c_i32),
+                ("reserved", c_i32), ("drop_state", c_vp)]
+
+
 class DiscLossShape(ctypes.Structure):
     _fields_ = [("B", c_i32), ("S", c_i32), ("N", c_i32), ("K", c_i32), ("n_update", c_i32), ("n_root", c_i32),
                 ("max_child", c_i32)]
@@ -85,6 +90,10 @@ SIGNATURES = {
     "bg_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "bg_layernorm_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_sz,
                                  c_vp]),
+    "bg_add_layernorm_dropout_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                             ctypes.POINTER(RowDropout), c_vp]),
+    "bg_layernorm_dropout_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                         c_sz, ctypes.POINTER(RowDropout), c_vp]),
     "bg_layernorm_bwd_groups": (c_i32, [c_i64]),
     "bg_bias_act_bwd_groups": (c_i32, [c_i64]),
     "bg_partial_reduce": (c_i32, [ctypes.POINTER(ReduceDesc), c_i32, c_vp]),

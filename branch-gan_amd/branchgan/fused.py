@@ -264,11 +264,22 @@ def supported_width(C_):
 # ---------------------------------------------------------------------------------------------------------------------
 # LayerNorm (+ residual add)
 # ---------------------------------------------------------------------------------------------------------------------
-def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None, pair=None, y_b=None):
-    """pair = (gamma_b, beta_b): a second LayerNorm of the same rows (-> y_b, returned last)."""
+def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None, pair=None, y_b=None, drop=None):
+    """pair = (gamma_b, beta_b): a second LayerNorm of the same rows (-> y_b, returned last).
+    drop = (p, site, row0, text_rows, rows_per_batch): delta enters through a dropout (bg_add_layernorm_dropout_fwd)."""
     rows, C_ = x2.shape
     if y is None:
         y = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
+    if drop is not None:
+        mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+        x_out = torch.empty_like(x2)
+        desc = ops.row_dropout_struct(drop, x2.device)
+        with ops._timed("add_layernorm_fwd"):
+            C.check(C.lib().bg_add_layernorm_dropout_fwd(C.ptr(x2), C.ptr(delta2), C.dtype_code(delta2), rows, C_, C.ptr(gamma), C.ptr(beta), float(eps),
+                                                         C.ptr(x_out), C.ptr(y), C.dtype_code(y), C.ptr(mean), C.ptr(rstd), ctypes.byref(desc),
+                                                         C.stream_ptr()), "bg_add_layernorm_dropout_fwd")
+        return x_out, y, mean, rstd
     if pair is not None and y_b is None:
         y_b = torch.empty((rows, C_), dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
@@ -284,11 +295,13 @@ def _ln_fwd(x2, delta2, gamma, beta, eps, out_dtype, second=None, y=None, pair=N
     return x_out, y, mean, rstd
 
 
-def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None, delta_from=None):
+def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None, delta_from=None, drop=None):
     rows, C_ = x2.shape
     dx = torch.empty_like(x2)
     dx_lp = None
-    if lp_dtype not in (None, torch.float32):
+    if drop is not None or lp_dtype not in (None, torch.float32):
+        if lp_dtype is None:
+            lp_dtype = torch.float32        # through a dropout the delta's gradient is not the residual stream's: its own tensor
         if delta_from is not None:          # the gradient of the projection that produced delta: into its dy stack
             dx_lp = _deferred_dw_for(x2.device).dy_slab(delta_from[0], delta_from[1], rows, C_, lp_dtype)
         if dx_lp is None:
@@ -303,10 +316,15 @@ def _ln_bwd(dy2, x2, mean, rstd, gamma_p, beta_p, dres2, lp_dtype, colsum_p=None
         later = None
     ws = later.alloc(nbytes) if later is not None else _workspace(nbytes, x2.device)
     with ops._timed("layernorm_bwd"):
-        C.check(lib.bg_layernorm_bwd(C.ptr(dy2), C.dtype_code(dy2), C.ptr(x2), C.ptr(mean), C.ptr(rstd), C.ptr(gamma_p.detach()),
-                                     C.ptr(dres2), rows, C_, C.ptr(dx), C.ptr(dx_lp), C.dtype_code(dx_lp) if dx_lp is not None else 0,
-                                     *((None, None, None, int(dc is not None)) if later is not None else (C.ptr(dg), C.ptr(db), C.ptr(dc), 0)),
-                                     C.ptr(ws), ws.numel(), C.stream_ptr()), "bg_layernorm_bwd")
+        common = (C.ptr(dy2), C.dtype_code(dy2), C.ptr(x2), C.ptr(mean), C.ptr(rstd), C.ptr(gamma_p.detach()),
+                  C.ptr(dres2), rows, C_, C.ptr(dx), C.ptr(dx_lp), C.dtype_code(dx_lp) if dx_lp is not None else 0,
+                  *((None, None, None, int(dc is not None)) if later is not None else (C.ptr(dg), C.ptr(db), C.ptr(dc), 0)),
+                  C.ptr(ws), ws.numel())
+        if drop is not None:
+            desc = ops.row_dropout_struct(drop, x2.device)
+            C.check(lib.bg_layernorm_dropout_bwd(*common, ctypes.byref(desc), C.stream_ptr()), "bg_layernorm_dropout_bwd")
+        else:
+            C.check(lib.bg_layernorm_bwd(*common, C.stream_ptr()), "bg_layernorm_bwd")
     if later is not None:
         groups, stride, base = lib.bg_layernorm_bwd_groups(rows), (3 if dc is not None else 2) * C_, ws.data_ptr()
         for i, out in enumerate((dg, db, dc)):
@@ -338,12 +356,18 @@ class _AddLayerNorm(torch.autograd.Function):
     delta's gradient, which this backward has in registers anyway - the projection is then built with bias_grad=False."""
 
     @staticmethod
-    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias, delta_b, y_buf=None, delta_from=None):
+    def forward(ctx, x, delta, gamma, beta, eps, out_dtype, delta_bias, delta_b, y_buf=None, delta_from=None, drop=None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         d2 = delta.reshape(x2.shape).contiguous()
         db2 = delta_b.reshape(x2.shape).to(delta.dtype).contiguous() if delta_b is not None else None
         ctx.two = delta_b is not None
-        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype, db2, y=y_buf[0] if y_buf else None)
+        ctx.drop = drop
+        if drop is not None:
+            if delta_b is not None:
+                raise NotImplementedError("dropout inside the LayerNorm kernel: one delta")
+            if d2.dtype != out_dtype:
+                d2 = d2.to(out_dtype)
+        x_out, y, mean, rstd = _ln_fwd(x2, d2, gamma.detach(), beta.detach(), eps, out_dtype, db2, y=y_buf[0] if y_buf else None, drop=drop)
         ctx.save_for_backward(x_out, mean, rstd)
         ctx.params = (gamma, beta, delta_bias)
         ctx.delta_from = delta_from
@@ -358,22 +382,28 @@ class _AddLayerNorm(torch.autograd.Function):
         if delta_bias is not None and not delta_bias.requires_grad:
             delta_bias = None
         if dy is None and dx_new is None:
-            return None, None, None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None, None, None
         if dy is None:      # only the residual output was used
             dres = dx_new.reshape(x_out.shape).contiguous().float()
             dlp = dres.to(ctx.delta_dtype)
+            if ctx.drop is not None:
+                p, site, row0, text_rows, per_batch = ctx.drop
+                dlp = ops._dropout_rows_call(dlp.view(-1, per_batch, dlp.shape[-1]), p, site, row0, text_rows).view(dlp.shape)
             dc_ret = None
             if delta_bias is not None:
                 buf, dc_ret = _grad_buffer(delta_bias)
                 buf.add_(dlp.float().sum(0))
             return (dres.view(dx_new.shape), dlp.view(dx_new.shape), None, None, None, None, dc_ret,
-                    (dlp.view(dx_new.shape) if ctx.two else None), None, None)
+                    (dlp.view(dx_new.shape) if ctx.two else None), None, None, None)
         dres2 = dx_new.reshape(x_out.shape).contiguous().float() if dx_new is not None else None
-        dx, dx_lp, dg, db, dc = _ln_bwd(dy.reshape(x_out.shape).contiguous(), x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype,
-                                        delta_bias, ctx.delta_from)
+        dy2 = dy.reshape(x_out.shape).contiguous()
+        if ctx.drop is not None and dy2.dtype != ctx.delta_dtype:
+            dy2 = dy2.to(ctx.delta_dtype)
+        dx, dx_lp, dg, db, dc = _ln_bwd(dy2, x_out, mean, rstd, gamma, beta, dres2, ctx.delta_dtype,
+                                        delta_bias, ctx.delta_from, drop=ctx.drop)
         shape = dy.shape
         dd = (dx_lp if dx_lp is not None else dx).view(shape)
-        return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None), None, None
+        return dx.view(shape), dd, dg, db, None, None, dc, (dd if ctx.two else None), None, None, None
 
 
 class _AddLayerNormPair(torch.autograd.Function):
@@ -477,12 +507,15 @@ def layer_norm(x, ln, out_dtype, out_for=None):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps, out_dtype, (y_buf,) if y_buf is not None else None)
 
 
-def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None, delta_b=None, out_for=None, delta_from=None):
+def add_layer_norm(x, delta, ln, out_dtype, delta_bias=None, delta_b=None, out_for=None, delta_from=None, drop=None):
     """-> (x + delta [+ delta_b] [fp32], LayerNorm of it [out_dtype]).  delta_bias, delta_b: see _AddLayerNorm.  out_for: as in
-    layer_norm; delta_from: the weight of the projection that produced delta (its output gradient is written into its stack)."""
+    layer_norm; delta_from: the weight of the projection that produced delta (its output gradient is written into its stack).
+    drop = (p, site, row0, text_rows): delta enters through a dropout, x + dropout(delta), inside the kernels (x is (B, T, C))."""
     y_buf = _x_slab_for(out_for, x.numel() // x.shape[-1], x.shape[-1], out_dtype, x.device)
+    if drop is not None:
+        drop = (*drop[:4], x.shape[-2])
     return _AddLayerNorm.apply(x, delta, ln.weight, ln.bias, ln.eps, out_dtype, delta_bias, delta_b,
-                               (y_buf,) if y_buf is not None else None, _pass_of(delta_from, x.device))
+                               (y_buf,) if y_buf is not None else None, _pass_of(delta_from, x.device), drop)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -608,11 +608,13 @@ class NonResidualGPT2Block(nn.Module):
         hidden_states = a + hidden_states
         return hidden_states + self.mlp(self.ln_2(hidden_states)), present
 
-    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None, dropoutRate=None, drop_ctx=None):
+    def fused_forward(self, x, delta, delta_bias, dtype, lp, delta_from=None, dropoutRate=None, drop_ctx=None, delta_drop=None):
         """Same block on the fused kernels (branchgan.fused).  The residual stream enters as x + delta (delta = the previous
         block's MLP output - of the projection with weight delta_from -, None for the first block) and leaves as (x2, m): the add is done by the next LayerNorm kernel.
-        -> (x2, m, bias of m's projection or None, present, weight of m's projection or None): the last two are None when a
-        dropout sits between that projection and the residual add (the LayerNorm backward's shortcuts then do not apply).
+        -> (x2, m, bias of m's projection, present, weight of m's projection, dropout m enters the residual stream through or
+        None).  The dropouts in front of the two residual adds happen INSIDE the LayerNorm kernels that do the adds
+        (fused.add_layer_norm(drop=)): no launch of their own, and the projections' bias gradients still come out of the
+        LayerNorm backward.
         Dropouts as in the reference: attention probabilities (inside the attention kernels) and attention output always on
         at dropoutRate or the config's rates, the MLP's nn.Dropout in training mode only.  Their masks are functions of (step,
         site, logical row): drop_ctx = (model salt, text rows of this pass, logical number of its first tree row), ops.drop_site."""
@@ -625,25 +627,21 @@ class NonResidualGPT2Block(nn.Module):
         if delta is None:
             x1, h1 = x, fused.layer_norm(x, self.ln_1, dtype, out_for=at.c_attn.weight)
         else:
-            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias, out_for=at.c_attn.weight, delta_from=delta_from)
+            x1, h1 = fused.add_layer_norm(x, delta, self.ln_1, dtype, delta_bias, out_for=at.c_attn.weight, delta_from=delta_from,
+                                          drop=delta_drop)
         qkv = fused.linear(h1, at.c_attn.weight, at.c_attn.bias, "io", dtype).view(B, T, 3, at.num_heads, at.head_dim)
         a, present = fused.packed_attention(qkv, lp, at._scale(), out_for=at.c_proj.weight, qkv_from=at.c_attn.weight,
                                             p_drop=at._p_attn(dropoutRate), drop_site=site(ops.SITE_ATTN), drop_row0=row0)
         # the two projections that feed a residual add leave their bias gradient to the LayerNorm backward that follows
         p_res = at._p_resid(dropoutRate)
-        if p_res:
-            a = ops.dropout_rows(fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype), p_res, site(ops.SITE_RESID), row0, text_rows)
-            x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, out_for=self.mlp.c_fc.weight)
-        else:
-            a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
-            x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight)
+        a = fused.linear(a, at.c_proj.weight, at.c_proj.bias, "io", dtype, bias_grad=False)
+        x2, h2 = fused.add_layer_norm(x1, a, self.ln_2, dtype, at.c_proj.bias, out_for=self.mlp.c_fc.weight, delta_from=at.c_proj.weight,
+                                      drop=(p_res, site(ops.SITE_RESID), row0, text_rows) if p_res else None)
         g = fused.linear(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, "io", dtype, act="gelu_tanh", out_for=self.mlp.c_proj.weight)
-        if self.mlp.resid_pdrop and self.training:
-            delta = ops.dropout_rows(fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype), self.mlp.resid_pdrop,
-                                     site(ops.SITE_MLP), row0, text_rows)
-            return x2, delta, None, present, None
         delta = fused.linear(g, self.mlp.c_proj.weight, self.mlp.c_proj.bias, "io", dtype, bias_grad=False)
-        return x2, delta, self.mlp.c_proj.bias, present, self.mlp.c_proj.weight
+        p_mlp = self.mlp.resid_pdrop if self.training else 0.0
+        return x2, delta, self.mlp.c_proj.bias, present, self.mlp.c_proj.weight, \
+            ((p_mlp, site(ops.SITE_MLP), row0, text_rows) if p_mlp else None)
 
 
 class NonResidualGPT2Model(_LMBase):
@@ -697,13 +695,12 @@ class NonResidualGPT2LMHeadModel(_LMBase):
                 p_emb = dropoutRate if dropoutRate is not None else self.config.embd_pdrop
                 if p_emb:                                           # always on (NonResidualDiscriminatorBase.py:231-232)
                     x = ops.dropout_rows(x, p_emb, ops.drop_site(self._drop_salt, 0x1FF, ops.SITE_EMBED), row0, text_rows)
-                delta_from = None
+                delta_from = delta_drop = None
                 for i, block in enumerate(tr.h):
-                    x, delta, delta_bias, present, delta_from = block.fused_forward(x, delta, delta_bias, dtype,
-                                                                                    _layer_past(textualPast, i) if branch else None, delta_from,
-                                                                                    dropoutRate, drop_ctx)
+                    x, delta, delta_bias, present, delta_from, delta_drop = block.fused_forward(
+                        x, delta, delta_bias, dtype, _layer_past(textualPast, i) if branch else None, delta_from, dropoutRate, drop_ctx, delta_drop)
                     presents.append(present)
-                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias, delta_from=delta_from)
+                _, y = fused.add_layer_norm(x, delta, tr.ln_f, dtype, delta_bias, delta_from=delta_from, drop=delta_drop)
                 head = self.lm_head if returnLmLogits else self.valueHead
                 logits = fused.linear(y, head.weight, None, "oi", dtype)
             return SimpleNamespace(loss=None, logits=logits, past_key_values=tuple(presents) if use_cache else None,

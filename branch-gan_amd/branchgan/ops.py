@@ -311,6 +311,14 @@ def _dropout_rows_call(x, p, site, row0, text_rows):
     return y
 
 
+def row_dropout_struct(drop, device):
+    """drop = (p, site, row0, text_rows, rows_per_batch) -> the C descriptor of the LayerNorm kernels' dropout variants."""
+    d = C.RowDropout()
+    d.p, d.site, d.row0, d.text_rows, d.rows_per_batch = float(drop[0]), int(drop[1]) & 0x7FFFFFFF, int(drop[2]) & 0xFFFFFFFF, int(drop[3]), int(drop[4])
+    d.drop_state = dropout_state(device).data_ptr()
+    return d
+
+
 def dropout_rows(x, p, site, row0=0, text_rows=None):
     """Dropout over a (B, T, C) activation with the counter-based generator of the attention dropout (bg_dropout_rows): the
     first `text_rows` rows (default: all) are text positions, the rest are tree rows whose logical number starts at row0."""

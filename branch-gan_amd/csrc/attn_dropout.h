@@ -18,56 +18,13 @@
 // distinct 32-bit values (every step is a bijection), kept iff value >= p * 2^32.
 #pragma once
 #include "attn_common.h"
+#include "dropout_common.h"
 
 namespace bg {
-
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-
-__device__ __forceinline__ uint32_t mix_a(uint32_t x) {      // murmur3 fmix32
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ uint32_t mix_b(uint32_t x) {      // lowbias32
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-  return x;
-}
-
-struct DropKeys {
-  uint32_t k0, k1, thresh, row0;
-  float inv_keep;
-};
-
-__device__ __forceinline__ DropKeys drop_keys_of(const uint64_t* state, uint32_t site, uint32_t stream_id, float p, uint32_t row0) {
-  DropKeys d;
-  const uint64_t seed = state[0], step = state[1];
-  uint32_t c[4] = {site, stream_id, (uint32_t)step, (uint32_t)(step >> 32)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  d.k0 = c[0]; d.k1 = c[1];
-  // p in (0, 1): keep iff bits >= p * 2^32 (p * 2^32 < 2^32 fits; computed in double on the host side of the same formula)
-  d.thresh = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
-  d.inv_keep = 1.0f / (1.0f - p);
-  d.row0 = row0;
-  return d;
-}
 
 // Wave-uniform: every lane computes the same keys (the loads are scalar loads of kernel-argument pointers).
 __device__ __forceinline__ DropKeys drop_keys(const AttnArgs& a, int bh) {
   return drop_keys_of(a.sh.drop_state, a.sh.drop_call, (uint32_t)bh, a.sh.p_drop, a.sh.drop_row0);
-}
-
-// row: the call's own row number n * K + k; the call's drop_row0 moves it to the logical row the mask is a function of
-__device__ __forceinline__ uint32_t drop_row_key(const DropKeys& d, uint32_t row) { return mix_a((row + d.row0) ^ d.k0) + d.k1; }
-
-__device__ __forceinline__ bool drop_keep(const DropKeys& d, uint32_t row_key, uint32_t column) {
-  return mix_b(row_key + column * 0x9E3779B1u) >= d.thresh;
 }
 
 }  // namespace bg

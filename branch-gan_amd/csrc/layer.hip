@@ -10,6 +10,7 @@
 // Column reductions (dgamma, dbeta, dbias) are deterministic: per-workgroup partials in the caller's workspace, then a
 // second small kernel adds them in a fixed order into the fp32 gradient (accumulating: grad += sum).
 #include "common.h"
+#include "dropout_common.h"
 
 #include <vector>
 
@@ -55,10 +56,13 @@ struct LnFwdArgs {
   const float* gamma_b;   // optional second LayerNorm of the same row (parallel-residual blocks normalise x + delta twice)
   const float* beta_b;
   void* y_b;
+  RowDropArgs drop;       // DROP kernels: x + dropout(delta) (bg_add_layernorm_dropout_fwd)
 };
 
-// TD: dtype of delta (ignored when delta == nullptr), TY: dtype of y
-template <typename TD, typename TY, int NV>
+// TD: dtype of delta (ignored when delta == nullptr), TY: dtype of y.  DROP: delta passes through a dropout on its way into the
+// residual stream (mask = function of (step, site, batch, logical row, column), dropout_common.h) - the block's
+// `x + dropout(projection)` without a kernel and an activation round trip of its own.
+template <typename TD, typename TY, int NV, bool DROP = false>
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 4 + wave;
@@ -69,6 +73,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
   const TD* d2 = a.delta2 ? (const TD*)a.delta2 + r * C : nullptr;
   float v[NV][4];
   float s = 0.f;
+  [[maybe_unused]] DropKeys dk;
+  [[maybe_unused]] uint32_t row_key = 0;
+  if constexpr (DROP) row_key = row_drop_key(a.drop, r, dk);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * (lane + 64 * i);
@@ -79,6 +86,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
       if (d) {
         float dv[4];
         load4<TD>(d + c, dv);
+        if constexpr (DROP) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dv[j] = drop_keep(dk, row_key, (uint32_t)(c + j)) ? dv[j] * dk.inv_keep : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
         if (d2) {
@@ -145,11 +156,12 @@ struct LnBwdArgs {
   int64_t rows;
   int C;
   int wave_lds;     // LDS holds one [2 or 3][C] region per wave (set by the launcher when that fits 64 KB)
+  RowDropArgs drop; // DROP kernels: dx_lp and its column sums are the gradient of a delta that entered through a dropout
 };
 
 // TY: dtype of dy;  TL: dtype of the low-precision copy of dx (ignored when dx_lp == nullptr);  COLSUM: also the column sums
 // of dx as the preceding projection sees it (rounded to TL when dx_lp is given) - that projection's bias gradient
-template <typename TY, typename TL, int NV, bool COLSUM>
+template <typename TY, typename TL, int NV, bool COLSUM, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
   extern __shared__ float lds[];   // [2 or 3][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,6 +211,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
     }
     s1 = wave_sum(s1) * inv_c;
     s2 = wave_sum(s2) * inv_c;
+    [[maybe_unused]] DropKeys dk;
+    [[maybe_unused]] uint32_t row_key = 0;
+    if constexpr (DROP) row_key = row_drop_key(a.drop, r, dk);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = 4 * (lane + 64 * i);
@@ -207,6 +222,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[i][j] - s1 - xh[i][j] * s2) + rv[i][j];
         store4<float>(a.dx + r * C + c, o);
+        if constexpr (DROP) {                          // what delta's producer sees: the gradient through the dropout
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = drop_keep(dk, row_key, (uint32_t)(c + j)) ? o[j] * dk.inv_keep : 0.f;
+        }
         if (a.dx_lp) store4<TL>((TL*)a.dx_lp + r * C + c, o);
         if constexpr (COLSUM) {
 #pragma unroll
@@ -413,17 +432,17 @@ static int bias_groups(int64_t rows) {
   return (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
 }
 
-template <typename TD, typename TY>
+template <typename TD, typename TY, bool DROP = false>
 static void launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
   dim3 grid((unsigned)cdiv(a.rows, 4)), block(256);
   const int nv = (int)cdiv(a.C, 256);
-  if (nv <= 2) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 2>), grid, block, 0, st, a);
-  else if (nv <= 4) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 4>), grid, block, 0, st, a);
-  else if (nv <= 8) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 8>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 16>), grid, block, 0, st, a);
+  if (nv <= 2) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 2, DROP>), grid, block, 0, st, a);
+  else if (nv <= 4) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 4, DROP>), grid, block, 0, st, a);
+  else if (nv <= 8) hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 8, DROP>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((add_layernorm_fwd_kernel<TD, TY, 16, DROP>), grid, block, 0, st, a);
 }
 
-template <typename TY, typename TL, bool COLSUM>
+template <typename TY, typename TL, bool COLSUM, bool DROP = false>
 static void launch_ln_bwd2(const LnBwdArgs& a0, int G, hipStream_t st) {
   dim3 grid((unsigned)G), block(256);
   LnBwdArgs a = a0;
@@ -431,15 +450,15 @@ static void launch_ln_bwd2(const LnBwdArgs& a0, int G, hipStream_t st) {
   a.wave_lds = (4 * lds <= 65536 && a.C % 4 == 0) ? 1 : 0;
   if (a.wave_lds) lds *= 4;
   const int nv = (int)cdiv(a.C, 256);
-  if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2, COLSUM>), grid, block, lds, st, a);
-  else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4, COLSUM>), grid, block, lds, st, a);
-  else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 8, COLSUM>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 16, COLSUM>), grid, block, lds, st, a);
+  if (nv <= 2) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 2, COLSUM, DROP>), grid, block, lds, st, a);
+  else if (nv <= 4) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 4, COLSUM, DROP>), grid, block, lds, st, a);
+  else if (nv <= 8) hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 8, COLSUM, DROP>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<TY, TL, 16, COLSUM, DROP>), grid, block, lds, st, a);
 }
-template <typename TY, typename TL>
+template <typename TY, typename TL, bool DROP = false>
 static void launch_ln_bwd(const LnBwdArgs& a, int G, bool colsum, hipStream_t st) {
-  if (colsum) launch_ln_bwd2<TY, TL, true>(a, G, st);
-  else launch_ln_bwd2<TY, TL, false>(a, G, st);
+  if (colsum) launch_ln_bwd2<TY, TL, true, DROP>(a, G, st);
+  else launch_ln_bwd2<TY, TL, false, DROP>(a, G, st);
 }
 
 }  // namespace bg
@@ -449,16 +468,48 @@ using namespace bg;
 static bool dtype_ok(int d) { return d == BG_F32 || d == BG_BF16; }
 static bool al16(const void* p) { return p && (((uintptr_t)p) & 15) == 0; }
 
+// -> 0, or an error code with the message set: the row-dropout descriptor of the *_dropout_* entry points
+static int check_row_dropout(const bg_row_dropout* d, int64_t rows, const char* who, RowDropArgs* out) {
+  BG_REQUIRE(d && d->drop_state, "%s: null dropout descriptor / state", who);
+  BG_REQUIRE(d->p > 0.f && d->p < 1.f, "%s: p = %g is not in (0, 1)", who, (double)d->p);
+  BG_REQUIRE(d->rows_per_batch > 0 && rows % d->rows_per_batch == 0 && rows / d->rows_per_batch < 4096, "%s: %lld rows are not a whole number (< 4096) of batches of %d",
+             who, (long long)rows, d->rows_per_batch);
+  BG_REQUIRE(d->text_rows >= 0 && d->text_rows <= (1 << 20), "%s: text_rows %d", who, d->text_rows);
+  *out = RowDropArgs{d->drop_state, d->p, d->site, d->row0, d->text_rows, d->rows_per_batch};
+  return BG_OK;
+}
+
+static int add_layernorm_fwd_impl(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
+                                  const float* gamma, const float* beta, const float* gamma_b, const float* beta_b, float eps,
+                                  float* x_out, void* y, void* y_b, int y_dtype, float* mean, float* rstd, const bg_row_dropout* drop,
+                                  void* stream);
+
 extern "C" int bg_add_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C, const float* gamma,
                                     const float* beta, float eps, float* x_out, void* y, int y_dtype, float* mean, float* rstd,
                                     void* stream) {
-  return bg_add_layernorm_pair_fwd(x, delta, delta2, delta_dtype, rows, C, gamma, beta, nullptr, nullptr, eps, x_out, y, nullptr, y_dtype, mean, rstd,
-                                   stream);
+  return add_layernorm_fwd_impl(x, delta, delta2, delta_dtype, rows, C, gamma, beta, nullptr, nullptr, eps, x_out, y, nullptr, y_dtype, mean, rstd,
+                                nullptr, stream);
 }
 
 extern "C" int bg_add_layernorm_pair_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
                                          const float* gamma, const float* beta, const float* gamma_b, const float* beta_b, float eps,
                                          float* x_out, void* y, void* y_b, int y_dtype, float* mean, float* rstd, void* stream) {
+  return add_layernorm_fwd_impl(x, delta, delta2, delta_dtype, rows, C, gamma, beta, gamma_b, beta_b, eps, x_out, y, y_b, y_dtype, mean, rstd, nullptr,
+                                stream);
+}
+
+extern "C" int bg_add_layernorm_dropout_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C, const float* gamma,
+                                            const float* beta, float eps, float* x_out, void* y, int y_dtype, float* mean, float* rstd,
+                                            const bg_row_dropout* drop, void* stream) {
+  BG_REQUIRE(delta && drop, "bg_add_layernorm_dropout_fwd: delta and the dropout descriptor are required");
+  return add_layernorm_fwd_impl(x, delta, nullptr, delta_dtype, rows, C, gamma, beta, nullptr, nullptr, eps, x_out, y, nullptr, y_dtype, mean, rstd, drop,
+                                stream);
+}
+
+static int add_layernorm_fwd_impl(const float* x, const void* delta, const void* delta2, int delta_dtype, int64_t rows, int C,
+                                  const float* gamma, const float* beta, const float* gamma_b, const float* beta_b, float eps,
+                                  float* x_out, void* y, void* y_b, int y_dtype, float* mean, float* rstd, const bg_row_dropout* drop,
+                                  void* stream) {
   BG_REQUIRE(x && gamma && beta && y && mean && rstd, "bg_add_layernorm_fwd: null argument");
   BG_REQUIRE((y_b == nullptr) == (gamma_b == nullptr) && (y_b == nullptr) == (beta_b == nullptr) && (!y_b || (al16(gamma_b) && al16(beta_b) && (((uintptr_t)y_b) & 7) == 0)),
              "bg_add_layernorm_pair_fwd: gamma_b, beta_b and y_b are given together (16-byte aligned; 8 for a bf16 y_b), or all NULL");
@@ -469,9 +520,17 @@ extern "C" int bg_add_layernorm_pair_fwd(const float* x, const void* delta, cons
   BG_REQUIRE(!delta2 || (delta && (((uintptr_t)delta2) & 7) == 0), "bg_add_layernorm_fwd: delta2 without delta, or misaligned");
   BG_REQUIRE(al16(x) && al16(gamma) && al16(beta) && (!delta || (((uintptr_t)delta) & 7) == 0) && (!delta || al16(x_out)) && (((uintptr_t)y) & 7) == 0,
              "bg_add_layernorm_fwd: pointers must be 16-byte aligned (8 for bf16)");
-  LnFwdArgs a{x, delta, delta2, gamma, beta, x_out, y, mean, rstd, rows, C, eps, gamma_b, beta_b, y_b};
+  LnFwdArgs a{x, delta, delta2, gamma, beta, x_out, y, mean, rstd, rows, C, eps, gamma_b, beta_b, y_b, RowDropArgs{}};
   hipStream_t st = (hipStream_t)stream;
   const bool dbf = delta && delta_dtype == BG_BF16;
+  if (drop) {
+    if (int e = check_row_dropout(drop, rows, "bg_add_layernorm_dropout_fwd", &a.drop)) return e;
+    BG_REQUIRE(delta_dtype == y_dtype, "bg_add_layernorm_dropout_fwd: delta and y share a dtype (bf16 / bf16 or fp32 / fp32)");
+    if (dbf) launch_ln_fwd<bf16_t, bf16_t, true>(a, st);
+    else launch_ln_fwd<float, float, true>(a, st);
+    BG_CHECK_LAUNCH("bg_add_layernorm_dropout_fwd");
+    return BG_OK;
+  }
   if (y_dtype == BG_BF16) {
     if (dbf) launch_ln_fwd<bf16_t, bf16_t>(a, st);
     else launch_ln_fwd<float, bf16_t>(a, st);
@@ -490,10 +549,32 @@ extern "C" size_t bg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 
 extern "C" int bg_layernorm_bwd_groups(int64_t rows) { return rows > 0 ? ln_groups(rows) : 0; }
 
+static int layernorm_bwd_impl(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                              float* dbeta, float* dx_colsum, int deferred_colsum, void* workspace, size_t workspace_bytes,
+                              const bg_row_dropout* drop, void* stream);
+
 extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
                                 const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
                                 float* dbeta, float* dx_colsum, int deferred_colsum, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+  return layernorm_bwd_impl(dy, dy_dtype, x, mean, rstd, gamma, dres, rows, C, dx, dx_lp, lp_dtype, dgamma, dbeta, dx_colsum, deferred_colsum,
+                            workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int bg_layernorm_dropout_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                        const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                                        float* dbeta, float* dx_colsum, int deferred_colsum, void* workspace, size_t workspace_bytes,
+                                        const bg_row_dropout* drop, void* stream) {
+  BG_REQUIRE(drop && dx_lp, "bg_layernorm_dropout_bwd: the dropout descriptor and dx_lp (the gradient through the dropout) are required");
+  return layernorm_bwd_impl(dy, dy_dtype, x, mean, rstd, gamma, dres, rows, C, dx, dx_lp, lp_dtype, dgamma, dbeta, dx_colsum, deferred_colsum,
+                            workspace, workspace_bytes, drop, stream);
+}
+
+static int layernorm_bwd_impl(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* dres, int64_t rows, int C, float* dx, void* dx_lp, int lp_dtype, float* dgamma,
+                              float* dbeta, float* dx_colsum, int deferred_colsum, void* workspace, size_t workspace_bytes,
+                              const bg_row_dropout* drop, void* stream) {
   BG_REQUIRE(dy && x && mean && rstd && gamma && dx, "bg_layernorm_bwd: null argument");
   BG_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "bg_layernorm_bwd: dgamma and dbeta are given together, or both NULL (deferred reduction)");
   BG_REQUIRE(deferred_colsum == 0 || !dgamma, "bg_layernorm_bwd: deferred_colsum is for the deferred form (dgamma == NULL)");
@@ -509,10 +590,15 @@ extern "C" int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
   }
   const int G = ln_groups(rows);
   const bool colsum = dx_colsum != nullptr || deferred_colsum != 0;
-  LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, dx_lp, (float*)workspace, rows, C};
+  LnBwdArgs a{dy, x, mean, rstd, gamma, dres, dx, dx_lp, (float*)workspace, rows, C, 0, RowDropArgs{}};
   hipStream_t st = (hipStream_t)stream;
   const bool lbf = dx_lp && lp_dtype == BG_BF16;
-  if (dy_dtype == BG_BF16) {
+  if (drop) {
+    if (int e = check_row_dropout(drop, rows, "bg_layernorm_dropout_bwd", &a.drop)) return e;
+    BG_REQUIRE(dy_dtype == lp_dtype, "bg_layernorm_dropout_bwd: dy and dx_lp share a dtype (bf16 / bf16 or fp32 / fp32)");
+    if (lbf) launch_ln_bwd<bf16_t, bf16_t, true>(a, G, colsum, st);
+    else launch_ln_bwd<float, float, true>(a, G, colsum, st);
+  } else if (dy_dtype == BG_BF16) {
     if (lbf) launch_ln_bwd<bf16_t, bf16_t>(a, G, colsum, st);
     else launch_ln_bwd<bf16_t, float>(a, G, colsum, st);
   } else {

@@ -324,6 +324,31 @@ int bg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
                      const float* gamma, const float* dres, int64_t rows, int C,
                      float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta, float* dx_colsum,
                      int deferred_colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* The block's `x + dropout(projection)` inside the LayerNorm kernels (GPT-2: F.dropout(attn_output, resid_pdrop) before the
+ * residual add, NonResidualAttention.py:274-275 + NonResidualDiscriminatorBase.py:46-60; the MLP's nn.Dropout, transformers'
+ * GPT2MLP): forward  x_out = x + delta * keep / (1 - p), y = LayerNorm(x_out);  backward  dx as bg_layernorm_bwd, while dx_lp and
+ * dx_colsum - what delta's projection and its bias receive - carry dx * keep / (1 - p).  The mask is bg_dropout_rows' function
+ * of (drop_state, site, batch, logical row, column) with the rows laid out [batch][rows_per_batch] (rows = batch *
+ * rows_per_batch): no dropout launch, no second copy of the activation, and the projection's bias gradient still comes out of
+ * the LayerNorm backward.  delta / y (forward) and dy / dx_lp (backward) share a dtype (bf16 or fp32); dx_lp is required. */
+typedef struct bg_row_dropout {
+  float p;                    /* in (0, 1) */
+  uint32_t site;
+  uint32_t row0;              /* logical number of the first row that is not a text row */
+  int32_t text_rows;          /* rows [0, text_rows) of every batch are text positions */
+  int32_t rows_per_batch;
+  int32_t reserved;
+  const uint64_t* drop_state; /* device memory: [seed, step counter] */
+} bg_row_dropout;
+int bg_add_layernorm_dropout_fwd(const float* x, const void* delta, int delta_dtype, int64_t rows, int C,
+                                 const float* gamma, const float* beta, float eps,
+                                 float* x_out, void* y, int y_dtype, float* mean, float* rstd,
+                                 const bg_row_dropout* drop, void* stream);
+int bg_layernorm_dropout_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* dres, int64_t rows, int C,
+                             float* dx, void* dx_lp, int lp_dtype, float* dgamma, float* dbeta, float* dx_colsum,
+                             int deferred_colsum, void* workspace, size_t workspace_bytes,
+                             const bg_row_dropout* drop, void* stream);
 size_t bg_bias_act_bwd_workspace_bytes(int64_t rows, int C);
 int bg_bias_act_bwd(const void* dy, int dtype, int64_t rows, int C, int64_t dy_row_stride,
                     int act, const void* pre, void* dx, float* dbias,

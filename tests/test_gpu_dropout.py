@@ -393,3 +393,38 @@ def test_generator_forward_under_dropout_samples_without_autograd_and_matches_th
     ops.seed_dropout(22)
     root, *_ = tree.multiStepGenForward(gen, ids, [sampling.SamplingRule(2, sampling.SamplingTechniques.TOP_K, {})], "cuda", sparseIndex=sparse)
     assert abs(float(root.labelLogProbs.sum()) - float(sum(0 for _ in ()))) > 0 and not torch.allclose(root.children[0].logProbs.detach(), lp_d[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_kernels_with_dropout_equal_dropout_then_add_layernorm(dtype):
+    """x + dropout(delta) inside the LayerNorm kernels (bg_add_layernorm_dropout_fwd / bg_layernorm_dropout_bwd) against
+    bg_dropout_rows followed by the plain kernels: the same residual stream and LayerNorm output, and the same gradients for
+    x, delta, gamma, beta - fp32 to the last bit, bf16 to its rounding (the fused form does not round the scaled delta)."""
+    from branchgan import fused, ops
+    B, S, N, K, Cc, p = 2, 24, 3, 8, 256, 0.2
+    T = S + N * K
+    ops.seed_dropout(5)
+    site = ops.drop_site(2, 3, ops.SITE_MLP)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.randn(B, T, Cc, device="cuda", generator=g)
+    d0 = torch.randn(B, T, Cc, device="cuda", generator=g).to(dtype)
+    gy = torch.randn(B, T, Cc, device="cuda", generator=g).to(dtype)
+    gx = torch.randn(B, T, Cc, device="cuda", generator=g)
+    res = []
+    for fused_drop in (True, False):
+        ln = torch.nn.LayerNorm(Cc).cuda()
+        with torch.no_grad():
+            ln.weight.copy_(torch.linspace(0.5, 1.5, Cc)); ln.bias.copy_(torch.linspace(-0.2, 0.2, Cc))
+        x, d = x0.clone().requires_grad_(True), d0.clone().requires_grad_(True)
+        if fused_drop:
+            x1, y = fused.add_layer_norm(x, d, ln, dtype, drop=(p, site, ops.TREE_ROW_BASE, S))
+        else:
+            x1, y = fused.add_layer_norm(x, ops.dropout_rows(d, p, site, ops.TREE_ROW_BASE, S), ln, dtype)
+        torch.autograd.backward([x1, y], [gx, gy])
+        torch.cuda.synchronize()
+        res.append((x1.detach(), y.detach(), x.grad, d.grad, ln.weight.grad, ln.bias.grad))
+    tol = dict(rtol=0, atol=0) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for a, b in zip(*res):
+        torch.testing.assert_close(a.float(), b.float(), **tol)
+    kept = (res[0][3] != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.03
