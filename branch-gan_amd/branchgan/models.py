@@ -682,7 +682,7 @@ class NonResidualGPT2LMHeadModel(_LMBase):
         tr = self.transformer
         merged_text = getattr(textualPast, "merged_text", 0) if branch else 0
         if not branch or merged_text:
-            ops.dropout_new_pass()          # a forward over a text: fresh dropout sites for it and the tree passes that hang off it
+            ops.dropout_new_pass(input_ids.device)      # a forward over a text: fresh dropout sites for it and the tree passes that hang off it
         if _fused_eligible(self, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate):
             dtype = fused.compute_dtype(tr.wte.weight)
             fused.prepare_weights(self, dtype)

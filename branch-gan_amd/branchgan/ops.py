@@ -237,10 +237,14 @@ def new_model_salt():
     return next(_model_salts) & 0xFF
 
 
-def dropout_new_pass():
+def dropout_new_pass(device=None):
     """A new forward pass over a text begins: its dropout sites (and those of the branch steps / tree passes hanging off it)
-    get a fresh pass number.  Host-side: a captured graph keeps the numbers it was recorded with, the device counter moves."""
+    get a fresh pass number.  Host-side: a captured graph keeps the numbers it was recorded with, the device counter moves.
+    A caller that never advances the step counter itself (a plain loop over an LM) would see the 11-bit pass number wrap and
+    the masks repeat: the counter is advanced for it when the numbers run out."""
     global _drop_pass
+    if _drop_pass >= 0x7FE and device is not None and torch.device(device).type == "cuda":
+        dropout_advance(device)
     _drop_pass += 1
 
 

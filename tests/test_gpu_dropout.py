@@ -428,3 +428,21 @@ def test_layernorm_kernels_with_dropout_equal_dropout_then_add_layernorm(dtype):
         torch.testing.assert_close(a.float(), b.float(), **tol)
     kept = (res[0][3] != 0).float().mean().item()
     assert abs(kept - (1 - p)) < 0.03
+
+
+def test_pass_numbers_do_not_wrap_into_repeated_masks():
+    """A caller that never advances the step counter: after 2046 forwards over a text the pass numbers run out and the counter
+    is advanced on its behalf - the masks of pass 1 do not come back."""
+    from branchgan import ops
+    ops.seed_dropout(1)
+    ops.dropout_advance("cuda")
+    x = torch.ones(1, 4, 64, device="cuda")
+    ops.dropout_new_pass("cuda")
+    first = ops.dropout_rows(x, 0.5, ops.drop_site(1, 0, ops.SITE_EMBED))
+    step0 = int(ops.dropout_state("cuda")[1])
+    for _ in range(0x7FF):
+        ops.dropout_new_pass("cuda")
+    assert int(ops.dropout_state("cuda")[1]) == step0 + 1 and ops._drop_pass == 2
+    ops._drop_pass = 1
+    again = ops.dropout_rows(x, 0.5, ops.drop_site(1, 0, ops.SITE_EMBED))
+    assert not torch.equal(first, again)
