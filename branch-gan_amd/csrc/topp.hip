@@ -342,6 +342,46 @@ __device__ void scan_sums(const double* sum, int nb, double cum0, float p32, Cro
   }
 }
 
+// The row into registers: vector c of thread t covers elements (c * 1024 + t) * 4 - mis + {0..3}; outside [0, V): -1.
+// Every vector is REQUESTED before the first one is used (round 3: with the canonicalising `+ 0.0f` inside the branch that
+// guarded each load the compiler waited for every vector before it asked for the next - thirteen dependent round trips per
+// thread, the 8.5 us "row" phase of profiles/r2_c_topp_phases.txt; 2.6 us now).  No branch around the loads: the address is
+// clamped into the row's own 16-byte vectors (a vector that straddles an end of the row is read whole - an aligned 16-byte load
+// that holds one byte of the row cannot leave the row's pages) and the elements outside are masked afterwards, by two
+// wave-uniform tests (only the first vector can start before the row, only the last ones can end behind it) instead of 104
+// per-element range checks (whose masks spilled).
+__device__ __forceinline__ void topp_load_row(const float* p, int V, int mis, int tid, float (&x)[TOPP_NV][4]) {
+  const char* p_al = (const char*)(p - mis);
+  const int last = ((V + mis + 3) / 4 - 1) * 4 - mis;
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+    const unsigned off = (unsigned)(min(max(i0, -mis), last) + mis);
+    const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p_al + 4 * off));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[c][j] = raw[j];
+  }
+#pragma unroll
+  for (int c = 0; c < TOPP_NV; ++c) {
+    const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[c][j] += 0.0f;
+    if (c == 0 && mis) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j < 0) x[c][j] = -1.0f;
+    }
+    if ((c + 1) * TOPP_THREADS * 4 - mis > V) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j >= V) x[c][j] = -1.0f;
+    }
+  }
+}
+
+// BATCHED: the row's loads all in flight (topp_load_row); false: one vector after the other - the persistent leftover kernel
+// (topp_regs_todo_kernel) has no registers to spare for it (380 B of scratch against 92)
+template <bool BATCHED>
 __device__ __forceinline__ void topp_regs_row(const ToppArgs& a, const int64_t row) {
   __shared__ double h_sum[4096];
   __shared__ double e_sum[256];
@@ -374,17 +414,25 @@ __device__ __forceinline__ void topp_regs_row(const ToppArgs& a, const int64_t r
   TOPP_STAMP(0);
   const int mis = (int)((((uintptr_t)p) & 15) / 4);
   float x[TOPP_NV][4];
+  if constexpr (BATCHED) {
+    topp_load_row(p, V, mis, tid, x);
+  } else {
+#pragma unroll
+    for (int c = 0; c < TOPP_NV; ++c) {
+      const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
+      if (i0 >= 0 && i0 + 4 <= V) {
+        const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p + i0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[c][j] = raw[j] + 0.0f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[c][j] = (i0 + j >= 0 && i0 + j < V) ? p[i0 + j] + 0.0f : -1.0f;
+      }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < TOPP_NV; ++c) {
     const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-    if (i0 >= 0 && i0 + 4 <= V) {
-      const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p + i0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[c][j] = raw[j] + 0.0f;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[c][j] = (i0 + j >= 0 && i0 + j < V) ? p[i0 + j] + 0.0f : -1.0f;
-    }
     for (int b = 0; b < a.n_blocked; ++b) {
       const uint32_t d = blk[b] - (uint32_t)i0;
 #pragma unroll
@@ -657,14 +705,14 @@ __device__ __forceinline__ void topp_regs_row(const ToppArgs& a, const int64_t r
   TOPP_STAMP(10);  // merge + store
 }
 
-__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) { topp_regs_row(a, blockIdx.x); }
+__global__ __launch_bounds__(TOPP_THREADS) void topp_regs_kernel(ToppArgs a) { topp_regs_row<true>(a, blockIdx.x); }
 
 // The rows topp_list_kernel could not do: todo[0] of them, listed in todo[1 ..]; a few persistent workgroups walk the list
 // (normally empty: the launch then costs a few microseconds, not a workgroup of 1024 threads per row).
 __global__ __launch_bounds__(TOPP_THREADS) void topp_regs_todo_kernel(ToppArgs a, const int* todo) {
   const int count = todo[0];
   for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    topp_regs_row(a, todo[1 + i] & 0xFFFFFF);
+    topp_regs_row<false>(a, todo[1 + i] & 0xFFFFFF);
     __syncthreads();                                     // the next row reuses the shared arrays
   }
 }
@@ -730,17 +778,10 @@ __global__ __launch_bounds__(TOPP_THREADS) void topp_list_kernel(ToppArgs a, int
   TOPP_STAMP(0);
   const int mis = (int)((((uintptr_t)p) & 15) / 4);
   float x[TOPP_NV][4];
+  topp_load_row(p, V, mis, tid, x);
 #pragma unroll
   for (int c = 0; c < TOPP_NV; ++c) {
     const int i0 = (c * TOPP_THREADS + tid) * 4 - mis;
-    if (i0 >= 0 && i0 + 4 <= V) {
-      const f32x4 raw = __builtin_nontemporal_load((const f32x4*)(p + i0));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[c][j] = raw[j] + 0.0f;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[c][j] = (i0 + j >= 0 && i0 + j < V) ? p[i0 + j] + 0.0f : -1.0f;
-    }
     for (int b = 0; b < a.n_blocked; ++b) {
       const uint32_t d = blk[b] - (uint32_t)i0;
 #pragma unroll
