@@ -76,16 +76,30 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
   [[maybe_unused]] DropKeys dk;
   [[maybe_unused]] uint32_t row_key = 0;
   if constexpr (DROP) row_key = row_drop_key(a.drop, r, dk);
+  // Every load of the row is REQUESTED before the first one is used (round 3): with the adds inside the `c < C` branch that
+  // guards each vector the compiler waited for a vector before it asked for the next - up to six dependent round trips for a
+  // 768-wide row with a delta, which is most of the life of the 256-row launches of a level pass.
+  typedef typename V4<TD>::type DV;
+  DV rd[NV], rd2[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * (lane + 64 * i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) { v[i][j] = 0.f; rd[i][j] = from_f32<TD>(0.f); rd2[i][j] = from_f32<TD>(0.f); }
     if (c < C) {
       load4<float>(x + c, v[i]);
+      if (d) rd[i] = *(const DV*)(d + c);
+      if (d2) rd2[i] = *(const DV*)(d2 + c);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    if (c < C) {
       if (d) {
         float dv[4];
-        load4<TD>(d + c, dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dv[j] = (float)rd[i][j];
         if constexpr (DROP) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) dv[j] = drop_keep(dk, row_key, (uint32_t)(c + j)) ? dv[j] * dk.inv_keep : 0.f;
@@ -93,9 +107,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
         if (d2) {
-          load4<TD>(d2 + c, dv);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[i][j] += dv[j];
+          for (int j = 0; j < 4; ++j) v[i][j] += (float)rd2[i][j];
         }
         store4<float>(a.x_out + r * C + c, v[i]);
       }
@@ -122,22 +135,39 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(LnFwdArgs a) {
     a.rstd[r] = rstd;
   }
   TY* y = (TY*)a.y + r * C;
+  // gamma / beta of four vectors at a time, all requested before the first is used (same reason as above)
+  constexpr int CH = NV < 4 ? NV : 4;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = 4 * (lane + 64 * i);
-    if (c < C) {
-      float g[4], b[4], o[4];
-      load4<float>(a.gamma + c, g);
-      load4<float>(a.beta + c, b);
+  for (int i0 = 0; i0 < NV; i0 += CH) {
+    float g[CH][4], b[CH][4], g2[CH][4], b2[CH][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-      store4<TY>(y + c, o);
-      if (a.y_b) {
-        load4<float>(a.gamma_b + c, g);
-        load4<float>(a.beta_b + c, b);
+    for (int k = 0; k < CH; ++k) {
+      const int c = 4 * (lane + 64 * (i0 + k));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-        store4<TY>((TY*)a.y_b + r * C + c, o);
+      for (int j = 0; j < 4; ++j) g[k][j] = b[k][j] = g2[k][j] = b2[k][j] = 0.f;
+      if (c < C) {
+        load4<float>(a.gamma + c, g[k]);
+        load4<float>(a.beta + c, b[k]);
+        if (a.y_b) {
+          load4<float>(a.gamma_b + c, g2[k]);
+          load4<float>(a.beta_b + c, b2[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int i = i0 + k;
+      const int c = 4 * (lane + 64 * i);
+      if (c < C) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[k][j] + b[k][j];
+        store4<TY>(y + c, o);
+        if (a.y_b) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g2[k][j] + b2[k][j];
+          store4<TY>((TY*)a.y_b + r * C + c, o);
+        }
       }
     }
   }

@@ -43,17 +43,7 @@ __global__ __launch_bounds__(256) void softmax_stats_fwd_kernel(const T* logits,
   const int mis = (int)((((uintptr_t)x) & 15) / sizeof(T));
   const int64_t vbegin = -mis;
   float m = -INFINITY, s = 0.f;
-  for (int64_t cb = vbegin; cb < V; cb += 256 * VEC) {
-    const int64_t i0 = cb + (int64_t)tid * VEC;
-    float v[VEC];
-    if (i0 >= 0 && i0 + VEC <= V) {
-      typename Vec<T>::type raw = *(const typename Vec<T>::type*)(x + i0);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? to_f32(x[i0 + j]) : -INFINITY;
-    }
+  auto fold = [&](const float (&v)[VEC]) __attribute__((always_inline)) {
     float vm = v[0];
 #pragma unroll
     for (int j = 1; j < VEC; ++j) vm = fmaxf(vm, v[j]);
@@ -65,7 +55,40 @@ __global__ __launch_bounds__(256) void softmax_stats_fwd_kernel(const T* logits,
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s += __expf(v[j] - m);
     }
+  };
+  auto guarded = [&](int64_t cb) __attribute__((always_inline)) {      // a chunk that may straddle an end of the row
+    const int64_t i0 = cb + (int64_t)tid * VEC;
+    float v[VEC];
+    if (i0 >= 0 && i0 + VEC <= V) {
+      typename Vec<T>::type raw = *(const typename Vec<T>::type*)(x + i0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? to_f32(x[i0 + j]) : -INFINITY;
+    }
+    fold(v);
+  };
+  // Chunks that lie wholly inside the row go four at a time, their loads requested before the first is folded (round 3: one
+  // load per iteration with the exponentials behind it left a single vector in flight per wave); a thread still folds its
+  // vectors in increasing order, so the result is the same to the bit.
+  constexpr int64_t CH = 256 * VEC;
+  constexpr int U = 4;
+  int64_t cb = vbegin;
+  if (cb < 0) { guarded(cb); cb += CH; }
+  for (; cb + U * CH <= V; cb += U * CH) {
+    typename Vec<T>::type raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) raw[u] = *(const typename Vec<T>::type*)(x + cb + u * CH + (int64_t)tid * VEC);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[u][j];
+      fold(v);
+    }
   }
+  for (; cb < V; cb += CH) guarded(cb);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ms_combine(m, s, __shfl_xor(m, o), __shfl_xor(s, o));
   if (lane == 0) { red_m[wave] = m; red_s[wave] = s; }
@@ -114,19 +137,7 @@ __global__ __launch_bounds__(256) void softmax_stats_bwd_kernel(const T* logits,
   const int mis = (int)((((uintptr_t)x) & 15) / sizeof(T));
   const bool out_vec_ok = ((((uintptr_t)dx) & 15) / sizeof(T)) == (unsigned)mis;
   const int64_t vbegin = -mis;
-  for (int64_t cb = vbegin; cb < V; cb += 256 * VEC) {
-    const int64_t i0 = cb + (int64_t)tid * VEC;
-    if (i0 >= V || i0 + VEC <= 0) continue;
-    const bool full = (i0 >= 0 && i0 + VEC <= V);
-    float v[VEC];
-    if (full) {
-      typename Vec<T>::type raw = *(const typename Vec<T>::type*)(x + i0);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? to_f32(x[i0 + j]) : 0.f;
-    }
+  auto finish = [&](int64_t i0, float (&v)[VEC], bool full) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = c * __expf(v[j] - lse);
     for (int i = 0; i < n_ids; ++i) {
@@ -146,7 +157,40 @@ __global__ __launch_bounds__(256) void softmax_stats_bwd_kernel(const T* logits,
       for (int j = 0; j < VEC; ++j)
         if (i0 + j >= 0 && i0 + j < V) dx[i0 + j] = from_f32<T>(v[j]);
     }
+  };
+  auto guarded = [&](int64_t cb) __attribute__((always_inline)) {
+    const int64_t i0 = cb + (int64_t)tid * VEC;
+    if (i0 >= V || i0 + VEC <= 0) return;
+    const bool full = (i0 >= 0 && i0 + VEC <= V);
+    float v[VEC];
+    if (full) {
+      typename Vec<T>::type raw = *(const typename Vec<T>::type*)(x + i0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (i0 + j >= 0 && i0 + j < V) ? to_f32(x[i0 + j]) : 0.f;
+    }
+    finish(i0, v, full);
+  };
+  // chunks wholly inside the row: four at a time, loads first (see the forward kernel)
+  constexpr int64_t CH = 256 * VEC;
+  constexpr int U = 4;
+  int64_t cb = vbegin;
+  if (cb < 0) { guarded(cb); cb += CH; }
+  for (; cb + U * CH <= V; cb += U * CH) {
+    typename Vec<T>::type raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) raw[u] = *(const typename Vec<T>::type*)(x + cb + u * CH + (int64_t)tid * VEC);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[u][j];
+      finish(cb + u * CH + (int64_t)tid * VEC, v, true);
+    }
   }
+  for (; cb < V; cb += CH) guarded(cb);
 }
 
 }  // namespace bg
