@@ -173,23 +173,12 @@ __global__ __launch_bounds__(256) void softmax_stats_bwd_kernel(const T* logits,
     }
     finish(i0, v, full);
   };
-  // chunks wholly inside the row: four at a time, loads first (see the forward kernel)
+  // One chunk per iteration here, unlike the forward kernel: the four-at-a-time form of this loop (loads first) was
+  // bit-identical and 2x faster at 256 rows, but with it the configs[3] step stopped making progress whenever the two backward
+  // graphs were replayed side by side (this kernel beside the discriminator's GEMMs; fine alone, fine with the graphs in
+  // turn) - not understood, so not shipped.
   constexpr int64_t CH = 256 * VEC;
-  constexpr int U = 4;
   int64_t cb = vbegin;
-  if (cb < 0) { guarded(cb); cb += CH; }
-  for (; cb + U * CH <= V; cb += U * CH) {
-    typename Vec<T>::type raw[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) raw[u] = *(const typename Vec<T>::type*)(x + cb + u * CH + (int64_t)tid * VEC);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float v[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) v[j] = (float)raw[u][j];
-      finish(cb + u * CH + (int64_t)tid * VEC, v, true);
-    }
-  }
   for (; cb < V; cb += CH) guarded(cb);
 }
 
