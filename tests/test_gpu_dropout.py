@@ -240,14 +240,16 @@ def test_rejected_shapes():
 
 
 def test_captured_step_with_attention_dropout_draws_fresh_masks_and_matches_eager():
-    """A GPT-2 Branch-GAN step with attn_pdrop = 0.1 captured into HIP graphs: (i) on the same (seed, counter) a replay
+    """A GPT-2 Branch-GAN step with the stock dropout rates (0.1 everywhere) captured into HIP graphs: (i) on the same (seed, counter) a replay
     reproduces the eager step - every loss and every element of both gradient arenas, so backward regenerates the forward's
     masks inside the graphs too; (ii) the counter advances inside the captured region: two replays on the same batch differ."""
     import dataclasses
     from branchgan import configs, gan, ops, sampling, training
     from branchgan.graphs import GraphedTrainStep
     torch.manual_seed(0)
-    cfg = dataclasses.replace(configs.LMConfig.from_any("gpt2-tiny"), attn_pdrop=0.1)
+    # the stock GPT-2 rates: attention probabilities (attention kernels), attention output and MLP output (LayerNorm kernels),
+    # embeddings (bg_dropout_rows)
+    cfg = dataclasses.replace(configs.LMConfig.from_any("gpt2-tiny"), attn_pdrop=0.1, resid_pdrop=0.1, embd_pdrop=0.1)
     model = gan.GannSetup(cfg, cfg, mleLossWeight=1, rlLossWeight=1, discValueHeadLossWeight=0.25, device="cuda").cuda()
     rules = [sampling.SamplingRule(1, sampling.SamplingTechniques.TOP_K, {}) for _ in range(3)]
     conf = configs.SamplingConfig(rules, includeAllMultiStepSamplesForDisc=True, numSampleSequences=8, seed=77)
