@@ -65,10 +65,22 @@ def _merge_heads(x):
     return x.permute(0, 2, 1, 3).reshape(b, t, h * d)
 
 
-def lm_forward(sd, prefix, cfg, input_ids, position_ids=None, textual_past=None, mask=None, lm_logits=True):
+def _dropped(x, entry):
+    """F.dropout with the Bernoulli draw handed in: entry = (keep, p) -> x * keep / (1 - p); None -> x."""
+    if entry is None:
+        return x
+    keep, p = entry
+    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
+def lm_forward(sd, prefix, cfg, input_ids, position_ids=None, textual_past=None, mask=None, lm_logits=True, drop=None):
     """One forward of the LM.  textual_past: per layer (k_ctx, v_ctx) => branch ("non-residual") mode
     (NeoXNonResidualBase.py:173-177, NonResidualDiscriminatorBase.py:181-185); None => root causal pass.
-    Returns (logits, presents, last_hidden) with presents = per layer (k, v) of the NEW tokens only."""
+    Returns (logits, presents, last_hidden) with presents = per layer (k, v) of the NEW tokens only.
+    drop (GPT-2, root pass): the reference's dropouts with their draws handed in - {"embed": (keep, p), ("attn", i): (keep, p)
+    on the attention probabilities (NonResidualAttention.py:107-109), ("resid", i) on the attention block's output (:274-275),
+    ("mlp", i) GPT2MLP's nn.Dropout}; torch's generator cannot be matched, so parity tests give both sides the same draw."""
+    drop = drop or {}
     B, T = input_ids.shape
     branch = textual_past is not None
     if position_ids is None:
@@ -103,6 +115,7 @@ def lm_forward(sd, prefix, cfg, input_ids, position_ids=None, textual_past=None,
         head = g("embed_out.weight") if lm_logits else g("valueHead.weight")
     else:
         x = F.embedding(input_ids, g("transformer.wte.weight")) + F.embedding(position_ids, g("transformer.wpe.weight"))
+        x = _dropped(x, drop.get("embed"))                                         # NonResidualDiscriminatorBase.py:231-232
         for i in range(cfg.n_layer):
             L = f"transformer.h.{i}."
             h1 = F.layer_norm(x, (cfg.hidden,), g(L + "ln_1.weight"), g(L + "ln_1.bias"), cfg.ln_eps)
@@ -114,11 +127,12 @@ def lm_forward(sd, prefix, cfg, input_ids, position_ids=None, textual_past=None,
             if branch:
                 o, _ = A.branch_attention(A.GPT2, q, k, v, textual_past[i][0], textual_past[i][1], mask, **kw)
             else:
-                o, _ = A.causal_attention(A.GPT2, q, k, v, **kw)
-            x = x + (_merge_heads(o) @ g(L + "attn.c_proj.weight") + g(L + "attn.c_proj.bias"))
+                ad = drop.get(("attn", i))
+                o, _ = A.causal_attention(A.GPT2, q, k, v, keep=ad[0] if ad else None, p_drop=ad[1] if ad else 0.0, **kw)
+            x = x + _dropped(_merge_heads(o) @ g(L + "attn.c_proj.weight") + g(L + "attn.c_proj.bias"), drop.get(("resid", i)))
             h2 = F.layer_norm(x, (cfg.hidden,), g(L + "ln_2.weight"), g(L + "ln_2.bias"), cfg.ln_eps)
             m = gelu_new(h2 @ g(L + "mlp.c_fc.weight") + g(L + "mlp.c_fc.bias")) @ g(L + "mlp.c_proj.weight") + g(L + "mlp.c_proj.bias")
-            x = x + m
+            x = x + _dropped(m, drop.get(("mlp", i)))
         x = F.layer_norm(x, (cfg.hidden,), g("transformer.ln_f.weight"), g("transformer.ln_f.bias"), cfg.ln_eps)
         head = g("lm_head.weight") if lm_logits else g("valueHead.weight")
     return F.linear(x, head), presents, x

@@ -448,3 +448,61 @@ def test_pass_numbers_do_not_wrap_into_repeated_masks():
     ops._drop_pass = 1
     again = ops.dropout_rows(x, 0.5, ops.drop_site(1, 0, ops.SITE_EMBED))
     assert not torch.equal(first, again)
+
+
+def test_gpt2_lm_under_stock_dropout_matches_the_oracle_given_the_same_draws():
+    """The GPT-2 LM's root pass with the stock rates on the fused path - embedding dropout (bg_dropout_rows), attention
+    probabilities (attention kernel), attention output and MLP output (LayerNorm kernels) - against the CPU oracle
+    (oracle.models.lm_forward, the reference's op order) that is handed the SAME Bernoulli draws, regenerated here from the
+    sites the model uses: logits and every parameter gradient to fp32 tolerance.  The reference's own draw comes from torch's
+    generator inside F.dropout and cannot be reproduced; what is held to the oracle is everything else."""
+    import dataclasses
+    from branchgan import configs, models, ops
+    from oracle import models as OM
+    torch.manual_seed(3)
+    p = 0.1
+    cfg = dataclasses.replace(configs.LMConfig.from_any("gpt2-tiny"), attn_pdrop=p, resid_pdrop=p, embd_pdrop=p)
+    lm = models.make_lm(cfg).cuda()
+    lm.train()
+    lm._drop_salt = 1
+    B, T = 2, 40
+    ids = torch.randint(0, cfg.vocab_size, (B, T), generator=torch.Generator().manual_seed(4))
+    ops.seed_dropout(9)
+    ops.dropout_advance("cuda")
+    logits = lm(input_ids=ids.cuda(), returnLmLogits=True).logits
+    assert ops._drop_pass == 1                                 # the pass number the sites of this forward carry
+    w = torch.randn(logits.shape, generator=torch.Generator().manual_seed(5))
+    (logits.float() * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+
+    # the draws, regenerated from (seed, step, site): ones through the same functions
+    H, Dh, C = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size
+    ones = torch.ones(B, T, C, device="cuda")
+    rows_keep = lambda site: (ops.dropout_rows(ones, p, site) != 0).cpu()
+    drop = {"embed": (rows_keep(ops.drop_site(1, 0x1FF, ops.SITE_EMBED)), p)}
+    q5 = torch.zeros(B, H, 1, T, Dh, device="cuda")
+    kt = torch.zeros(B, H, T, Dh, device="cuda")
+    for i in range(cfg.num_hidden_layers):
+        drop[("resid", i)] = (rows_keep(ops.drop_site(1, i, ops.SITE_RESID)), p)
+        drop[("mlp", i)] = (rows_keep(ops.drop_site(1, i, ops.SITE_MLP)), p)
+        keep = _mask_of(ops, q5, kt, [], 0, ops.drop_descriptor(p, ops.drop_site(1, i, ops.SITE_ATTN), 0), 1.0)      # (B, H, T, T)
+        drop[("attn", i)] = (keep.bool(), p)
+    for k, (m, _) in drop.items():
+        assert abs(float(m.float().mean()) - (1 - p)) < 0.03, k
+
+    sd = {k: v.detach().cpu().float().requires_grad_(True) for k, v in lm.state_dict().items()}
+    ocfg = OM.LMConfig("gpt2", cfg.num_hidden_layers, H, C, cfg.vocab_size, cfg.max_position_embeddings)
+    ref, _, _ = OM.lm_forward(sd, "", ocfg, ids, drop=drop)
+    torch.testing.assert_close(logits.float().cpu(), ref, rtol=2e-4, atol=2e-4)
+    plain, _, _ = OM.lm_forward(sd, "", ocfg, ids)
+    assert float((plain - ref).detach().abs().max()) > 0.05     # the masks matter
+    (ref * w).sum().backward()
+    checked = 0
+    for name, prm in lm.named_parameters():
+        if prm.grad is None or name == "valueHead.weight":
+            continue
+        g_ref = sd[name].grad
+        err = float((prm.grad.cpu() - g_ref).abs().max()) / (float(g_ref.abs().max()) + 1e-12)
+        assert err < 2e-3, (name, err)
+        checked += 1
+    assert checked >= 2 + 12 * cfg.num_hidden_layers
