@@ -414,8 +414,10 @@ def _layer_past(textualPast, i):
 
 def _fused_eligible(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate=None):
     """The fused block path (branchgan.fused) covers the training hot path: fp32 parameters on the GPU (bf16 compute comes
-    from autocast), engine-form past; dropout on the attention probabilities runs inside the attention kernels, the residual
-    / embedding dropouts as ATen ops between the fused pieces.  Everything else runs module by module."""
+    from autocast), engine-form past; dropout on the attention probabilities runs inside the attention kernels; the GPT-2
+    family's residual / MLP dropouts inside the LayerNorm kernels and its embedding dropout through bg_dropout_rows (one
+    generator, masks by site), the NeoX blocks' nn.Dropouts as ATen ops between the fused pieces.  Everything else runs module
+    by module."""
     ok = _fused_covers(model, input_ids, textualPast, customCasualMask, output_hidden_states, dropoutRate)
     if not ok:
         fused.module_path_forwards += 1         # graphs.py: a step with module-by-module forwards is not replayed side by side
