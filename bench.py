@@ -159,7 +159,7 @@ def attention_roofline(rec, kind, dtype_name, device, workload_key, reps=5):
     achieved = tot_bytes / n / (avg_ms * 1e-3) / 1e9
     traffic, src = _pmc_traffic(f"r3_pmc_attn_{kind}_{workload_key}.json", n) if dtype_name == "bf16" else (None, None)
     entry = "bg_branch_attn_fwd (branch_attn_fwd_kernel / _split_kernel)" if kind == "fwd" else \
-        "bg_branch_attn_bwd (branch_attn_bwd_one_kernel: key tiles, query tiles and slot rows of a call in one grid; the split kernels at Dh 256)"
+        "bg_branch_attn_bwd (branch_attn_bwd_one_kernel: key tiles, query tiles and slot rows of a call in one grid; branch_attn_bwd_head_kernel for slot-free calls on >= 64 heads; the split kernels at Dh 256)"
     tf = tot_flops / n / (avg_ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": f"{entry}: one train step's recorded launch mix, timed in a side replay of the step's recorded launches "
                                       "(a HIP graph on its own stream, HIP events on that stream) after the timed region",
