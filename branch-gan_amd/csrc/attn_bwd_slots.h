@@ -11,26 +11,24 @@ namespace bg {
 // The query nodes whose path holds this slot are listed in LDS first (all threads test one node each: ballot + popcount keep
 // them in ascending order, so the sums below are taken in a fixed order); the list is then walked four members at a time
 // with all their loads issued together - a walk over every node with a dependent load per test was 17 us of latency.
+// (every vector of the row is requested before the first is converted: with the bf16 -> float conversion inside the `valid`
+// branch the compiler had waited for each 8-byte load before it asked for the next - round 3)
 template <typename T, int N>
 __device__ __forceinline__ void slot_load(float (&out)[N], const T* p, bool valid) {
+  typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x4>::type V;
+  V raw[N / 4];
 #pragma unroll
-  for (int c = 0; c < N / 4; ++c) {
-    if constexpr (sizeof(T) == 4) {
-      f32x4 raw = {0.f, 0.f, 0.f, 0.f};
-      if (valid) raw = *(const f32x4*)(p + 4 * c);
+  for (int c = 0; c < N / 4; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) out[4 * c + j] = raw[j];
-    } else {
-      float x[4] = {0.f, 0.f, 0.f, 0.f};
-      if (valid) {
-        const bf16x4 raw = *(const bf16x4*)(p + 4 * c);
+    for (int j = 0; j < 4; ++j) raw[c][j] = (T)0.0f;
+  if (valid) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = (float)raw[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) out[4 * c + j] = x[j];
-    }
+    for (int c = 0; c < N / 4; ++c) raw[c] = *(const V*)(p + 4 * c);
   }
+#pragma unroll
+  for (int c = 0; c < N / 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[4 * c + j] = (float)raw[c][j];
 }
 
 template <typename T, int N>
