@@ -430,13 +430,8 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(BiasActArgs a) {
   const int c = 4 * (blockIdx.y * 256 + threadIdx.x);      // grid.y column chunks of 1024
   if (c < C) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int64_t r = blockIdx.x; r < a.rows; r += G) {
-      float d[4];
-      load4<T>((const T*)a.dy + r * a.dy_stride + c, d);
+    auto one = [&](int64_t r, float (&d)[4], const float (&p)[4]) __attribute__((always_inline)) {
       if constexpr (MODE != 0) {
-        float p[4];
-        load4<T>((const T*)a.pre + r * C + c, p);
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] *= (MODE == 1) ? gelu_tanh_grad(p[j]) : gelu_erf_grad(p[j]);
         store4<T>((T*)a.dx + r * C + c, d);
@@ -446,6 +441,27 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(BiasActArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += d[j];
+    };
+    // Four rows at a time, their loads requested before the first is used (round 3): a thread's rows are G apart and each used
+    // to be one dependent round trip (the store of dx between two rows' loads keeps the compiler from moving them) - twelve in
+    // a row at 3072 rows.  Rows are still added in increasing order: same sums.
+    constexpr int UR = 4;
+    int64_t r = blockIdx.x;
+    for (; r + (UR - 1) * (int64_t)G < a.rows; r += (int64_t)UR * G) {
+      float d[UR][4], p[UR][4];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        load4<T>((const T*)a.dy + (r + u * (int64_t)G) * a.dy_stride + c, d[u]);
+        if constexpr (MODE != 0) load4<T>((const T*)a.pre + (r + u * (int64_t)G) * C + c, p[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) one(r + u * (int64_t)G, d[u], p[u]);
+    }
+    for (; r < a.rows; r += G) {
+      float d[4], p[4] = {0.f, 0.f, 0.f, 0.f};
+      load4<T>((const T*)a.dy + r * a.dy_stride + c, d);
+      if constexpr (MODE != 0) load4<T>((const T*)a.pre + r * C + c, p);
+      one(r, d, p);
     }
     store4<float>(part + c, acc);
   }
