@@ -49,9 +49,27 @@ struct HeadArgs {
   int parts;
 };
 
+// The incoming gradient of this lane's key row (what the tree pass sent back to the text keys / values), requested BEFORE the
+// tile loop: read inside the store, each 8-byte piece was a load waited for on the spot - sixteen dependent round trips at the
+// end of every key tile.
+template <int DH>
+struct RowIn {
+  bf16x4 v[DH / 8];
+  bool has;
+  __device__ __forceinline__ void load(const bf16_t* add, int h, bool valid) {
+    has = add != nullptr;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i) v[i] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (has && valid) {
+#pragma unroll
+      for (int i = 0; i < DH / 8; ++i) v[i] = *(const bf16x4*)(add + (i >> 2) * 32 + 8 * (i & 3) + 4 * h);
+    }
+  }
+};
+
 // dK or dV of this lane's key row: accumulators (rows = d) + optional incoming gradient -> global
 template <int DH>
-__device__ __forceinline__ void store_rowvec_add(const f32x16 (&acc)[DH / 32], bf16_t* row, const bf16_t* add, int h, bool valid) {
+__device__ __forceinline__ void store_rowvec_add(const f32x16 (&acc)[DH / 32], bf16_t* row, const RowIn<DH>& in, int h, bool valid) {
   if (!valid) return;
 #pragma unroll
   for (int dt = 0; dt < DH / 32; ++dt) {
@@ -61,10 +79,9 @@ __device__ __forceinline__ void store_rowvec_add(const f32x16 (&acc)[DH / 32], b
       float x[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = acc[dt][4 * g + j];
-      if (add) {
-        const bf16x4 t = *(const bf16x4*)(add + off);
+      if (in.has) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] += (float)t[j];
+        for (int j = 0; j < 4; ++j) x[j] += (float)in.v[dt * 4 + g][j];
       }
       bf16x4 o;
 #pragma unroll
@@ -257,6 +274,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void branch_attn_bwd_head_kernel(Head
     } else if (kind == 0) {
       // ---- dK / dV of key tile idx: this lane's key row against the query tiles that reach it -------------------------------------
       const int key0 = idx * ATT_TILE, key = key0 + (lane & 31);
+      const bool kvalid = key < S;
+      const int64_t off = t_off + (int64_t)key * sh.t_ss;
+      RowIn<DH> in_k, in_v;
+      in_k.load(a.dk_text_in ? (const T*)a.dk_text_in + off : nullptr, h, kvalid);
+      in_v.load(a.dv_text_in ? (const T*)a.dv_text_in + off : nullptr, h, kvalid);
       LdsRowFrag<T, DH> kf, vf;
       kf.load(k_l + key * RS);
       vf.load(v_l + key * RS);
@@ -292,10 +314,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void branch_attn_bwd_head_kernel(Head
         mma_reduce_rows_tr<DH, 0, NDT>(dv, s, do_tile, lane);        // dV^T += dO^T P
         mma_reduce_rows_tr<DH, 0, NDT>(dk, dp, q_tile, lane);        // dK^T += Q^T dS
       }
-      const bool kvalid = key < S;
-      const int64_t off = t_off + (int64_t)key * sh.t_ss;
-      store_rowvec_add<DH>(dk, (T*)a.dk_text + off, a.dk_text_in ? (const T*)a.dk_text_in + off : nullptr, h, kvalid);
-      store_rowvec_add<DH>(dv, (T*)a.dv_text + off, a.dv_text_in ? (const T*)a.dv_text_in + off : nullptr, h, kvalid);
+      store_rowvec_add<DH>(dk, (T*)a.dk_text + off, in_k, h, kvalid);
+      store_rowvec_add<DH>(dv, (T*)a.dv_text + off, in_v, h, kvalid);
     } else {
       // ---- dK / dV of slot idx: eight branch points at a time (eight lanes each, DH / 8 features a lane), over the member nodes ----
       constexpr int PER = DH / 8;

@@ -73,24 +73,44 @@ __device__ __forceinline__ void merge4(const float* mo, int row, int grp, float 
 }
 
 template <typename T, int PER>
-__device__ __forceinline__ void store_vec(T* p, const float (&acc)[PER], const T* add) {
+struct VecIn {                                            // PER incoming values of a row, requested ahead of their use
+  typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x4>::type V;
+  V v[PER / 4];
+  bool has;
+  __device__ __forceinline__ void load(const T* p, bool valid) {       // p null: nothing comes in
+    has = p != nullptr;
+#pragma unroll
+    for (int c = 0; c < PER / 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[c][j] = (T)0.f;
+    if (has && valid) {
+#pragma unroll
+      for (int c = 0; c < PER / 4; ++c) v[c] = *(const V*)(p + 4 * c);
+    }
+  }
+};
+
+template <typename T, int PER>
+__device__ __forceinline__ void store_vec(T* p, const float (&acc)[PER], const VecIn<T, PER>& in) {
 #pragma unroll
   for (int j0 = 0; j0 < PER; j0 += 4) {
     float x[4] = {acc[j0], acc[j0 + 1], acc[j0 + 2], acc[j0 + 3]};
-    if constexpr (sizeof(T) == 4) {
-      if (add) { const f32x4 t = *(const f32x4*)(add + j0); for (int j = 0; j < 4; ++j) x[j] += t[j]; }
-      f32x4 o;
+    if (in.has) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = x[j];
-      *(f32x4*)(p + j0) = o;
-    } else {
-      if (add) { const bf16x4 t = *(const bf16x4*)(add + j0); for (int j = 0; j < 4; ++j) x[j] += (float)t[j]; }
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)x[j];
-      *(bf16x4*)(p + j0) = o;
+      for (int j = 0; j < 4; ++j) x[j] += (float)in.v[j0 / 4][j];
     }
+    typename VecIn<T, PER>::V o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (T)x[j];
+    *(typename VecIn<T, PER>::V*)(p + j0) = o;
   }
+}
+
+template <typename T, int PER>
+__device__ __forceinline__ void store_vec(T* p, const float (&acc)[PER]) {
+  VecIn<T, PER> none;
+  none.load(nullptr, false);
+  store_vec<T, PER>(p, acc, none);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -272,7 +292,7 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
       float acc[PER];
       merge4<DH, PER>(mo, qi, grp, acc);
       T* dq_row = (T*)a.dq + (int64_t)b * sh.dq_sb + (int64_t)hh * sh.dq_sh + (int64_t)n2 * sh.dq_sn + (int64_t)k2 * sh.dq_sk + grp * PER;
-      store_vec<T, PER>(dq_row, acc, nullptr);
+      store_vec<T, PER>(dq_row, acc);
     }
   }
   BG_TRACE(0, 6);
@@ -585,8 +605,17 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
   const int ki = tid & 31, grp = tid >> 5;
   const int key2 = key0 + ki;
   const int64_t off2 = (int64_t)b * sh.t_sb + (int64_t)hh * sh.t_sh + (int64_t)key2 * sh.t_ss + DT0 * 32 + grp * PER;
+  // what comes in for this thread's piece of the key row (the tree pass's gradient of the text keys / values) is requested
+  // before the merge: read inside the store, each piece was a dependent round trip at the very end of the workgroup's life.
+  // Dh 256 holds 512 registers by now: its dV piece is requested once dK's has left.
+  VecIn<T, PER> in_k, in_v;
+  in_k.load(a.dk_text_in ? (const T*)a.dk_text_in + off2 : nullptr, key2 < sh.S_text);
+  if constexpr (DPASS <= 128) in_v.load(a.dv_text_in ? (const T*)a.dv_text_in + off2 : nullptr, key2 < sh.S_text);
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    if constexpr (DPASS > 128) {
+      if (which == 1) in_v.load(a.dv_text_in ? (const T*)a.dv_text_in + off2 : nullptr, key2 < sh.S_text);
+    }
     __syncthreads();                                     // staging (or the previous merge) no longer read
 #pragma unroll
     for (int dt = DT0; dt < DT1; ++dt)
@@ -598,8 +627,7 @@ __device__ __forceinline__ void bwd_dkv_tile(const AttnArgs& a, char* smem, int 
       float acc[PER];
       merge4<DPASS, PER>(mo, ki, grp, acc);
       T* out = (T*)(which == 0 ? a.dk_text : a.dv_text) + off2;
-      const void* inp = which == 0 ? a.dk_text_in : a.dv_text_in;
-      store_vec<T, PER>(out, acc, inp ? (const T*)inp + off2 : nullptr);
+      store_vec<T, PER>(out, acc, which == 0 ? in_k : in_v);
     }
     if (which == 0) BG_TRACE(1, 5);
   }

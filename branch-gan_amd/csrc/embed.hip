@@ -48,13 +48,24 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_first_kernel(const int64_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * EMBED_FIRST_ROWS;
   const int r_last = min(n - 1, r0 + EMBED_FIRST_ROWS - 1);          // only indices up to the last row of this workgroup matter
-  for (int j = threadIdx.x; j < ((r_last + 4) & ~3); j += EMBED_THREADS) {
-    int key = -1;
-    if (j <= r_last) {
-      const int64_t t = idx[(base + j) % idx_rows];
-      key = (t >= 0 && t < table_rows) ? (int)t : -(j + 3);
+  // four index loads in flight per thread (guarded one by one, each was a round trip of its own: twelve in a row at 3072 rows);
+  // the row of the index list is a 32-bit remainder when the list is short enough for that (it is for position ids)
+  const int lim = (r_last + 4) & ~3;
+  const bool narrow = idx_rows < (1ll << 31) - EMBED_CHUNK;
+  const unsigned base_mod = narrow ? (unsigned)(base % idx_rows) : 0u;
+  auto index_row = [&](int j) -> int64_t {
+    if (narrow) return (int64_t)((base_mod + (unsigned)j) % (unsigned)idx_rows);
+    return (base + j) % idx_rows;
+  };
+  for (int j0 = threadIdx.x; j0 < lim; j0 += 4 * EMBED_THREADS) {
+    int64_t t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = idx[index_row(min(j0 + u * EMBED_THREADS, r_last))];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * EMBED_THREADS;
+      if (j < lim) s_idx[j] = j > r_last ? -1 : (t[u] >= 0 && t[u] < table_rows) ? (int)t[u] : -(j + 3);
     }
-    s_idx[j] = key;
   }
   __syncthreads();
   const int r = r0 + lane;
@@ -93,10 +104,15 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_accum_kernel(const float*
   // which of the rows j >= r share the index: all loads in flight at once, one bit per slot
   const int j_begin = r & ~(EMBED_THREADS - 1);
   unsigned hits = 0;
+  {
+    int f[EMBED_SLOTS];                                  // (the address is clamped, not the load guarded: a guarded load is waited for
+#pragma unroll                                           // on the spot, and there are 32 of them)
+    for (int k = 0; k < EMBED_SLOTS; ++k) f[k] = first[min(max(j_begin + k * EMBED_THREADS + (int)threadIdx.x, r), n - 1)];
 #pragma unroll
-  for (int k = 0; k < EMBED_SLOTS; ++k) {
-    const int j = j_begin + k * EMBED_THREADS + threadIdx.x;
-    if (j >= r && j < n && first[j] == r) hits |= 1u << k;
+    for (int k = 0; k < EMBED_SLOTS; ++k) {
+      const int j = j_begin + k * EMBED_THREADS + threadIdx.x;
+      if (j >= r && j < n && f[k] == r) hits |= 1u << k;
+    }
   }
   const int c = 256 * blockIdx.y + 4 * lane;
   const bool live = c < C;
