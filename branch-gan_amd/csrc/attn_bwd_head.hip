@@ -255,18 +255,19 @@ __global__ __launch_bounds__(HEAD_THREADS) void branch_attn_bwd_head_kernel(Head
       // branch keys: the same branch point of every slot on this node's path
       const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;
       for (int p = 0; p < sh.max_path; ++p) {
-        const bool act = p < plen;
         const int slot = a.path[n * sh.max_path + p];
         const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
-        const T* kr = nullptr;
-        const T* vr = nullptr;
-        for (int sidx = 0; sidx < sh.n_slots; ++sidx)
-          if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
-        const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
-        const float dpv = pair_dot<T, DH>(do_row, vr, h, act);
+        const T* kr;
+        const T* vr;
+        slot_rows<T>(a, slot, p < plen, off, kr, vr);
+        const bool act = p < plen && kr;
+        BwdPathRow<T, DH> kv;                                        // key (both layouts) and value row in one round of loads
+        kv.load(kr, vr, h, act);
+        const float sc = kv.dot_k(q_row, h, act) * sh.scale;
+        const float dpv = kv.dot_v(do_row, h, act);
         if (act) {
           const float pw = __expf(sc - lse);
-          axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
+          kv.axpy_k(dq, pw * (dpv - delta) * sh.scale);
         }
       }
       T* dq_row = (T*)a.dq + (int64_t)b * sh.dq_sb + (int64_t)hh * sh.dq_sh + (int64_t)n * sh.dq_sn + (int64_t)kq * sh.dq_sk;

@@ -153,9 +153,17 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
   int ctx = valid ? a.ctx_len[kq] : 0;
   const float lse = valid ? a.lse[stat] : 0.f;
   const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
+  const int slot_first = wave < sh.max_path ? a.path[n * sh.max_path + wave] : 0;   // this wave's first path entry, in the same round
   TileRegs<T, DH, 64> kreg, vreg;
   typename std::conditional<SL::OWN, LdsRowFrag<T, DH>, RowFrag<T, DH>>::type qf, dof;   // own tile in LDS: read where used
   float delta;
+  // this lane's Q / dO rows for the branch keys: in LDS where the own tile stays there
+  const T* q_path = q_row;
+  const T* do_path = do_row;
+  if constexpr (SL::OWN) {
+    q_path = (const T*)(smem + SL::STAGE_BYTES) + (lane & 31) * Lds<T, DH>::RSTRIDE;
+    do_path = (const T*)(smem + SL::STAGE_BYTES + SL::TILE_BYTES) + (lane & 31) * Lds<T, DH>::RSTRIDE;
+  }
   if constexpr (SL::OWN || SL::PARK) {
     constexpr int VEC = 16 / sizeof(T), CPR = DH / VEC;
     // OWN: behind the staging area, for the kernel's life; PARK: in wave 0's staging region (delta in wave 1's) until the loop
@@ -256,19 +264,30 @@ __device__ __forceinline__ void bwd_dq_tile(const AttnArgs& a, char* smem, int t
   BG_TRACE(0, 3);
   // branch keys: path entries wave, wave + 4, ...
   for (int p = wave; p < sh.max_path; p += ATT_WAVES) {
-    const bool act = p < plen;
-    const int slot = a.path[n * sh.max_path + p];        // in bounds for every p < max_path: no wait on path_len first
+    const int slot = p == wave ? slot_first : a.path[n * sh.max_path + p];   // in bounds for every p < max_path: no wait on path_len first
     const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
-    const T* kr = nullptr;
-    const T* vr = nullptr;
-    for (int sidx = 0; sidx < sh.n_slots; ++sidx)
-      if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
-    const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
-    float dpv = pair_dot<T, DH>(do_row, vr, h, act);
+    const T* kr;
+    const T* vr;
+    slot_rows<T>(a, slot, p < plen, off, kr, vr);
+    const bool act = p < plen && kr;
+    // the key row (both layouts) and the value row in ONE round of loads where the registers allow: path entry -> slot pointer
+    // -> key -> value -> key again was five dependent round trips an entry
+    constexpr bool TOGETHER = DH * sizeof(T) <= 256;
+    float sc, dpv;
+    [[maybe_unused]] BwdPathRow<T, TOGETHER ? DH : 32> kv;
+    if constexpr (TOGETHER) {
+      kv.load(kr, vr, h, act);
+      sc = kv.dot_k(q_path, h, act) * sh.scale;
+      dpv = kv.dot_v(do_path, h, act);
+    } else {
+      sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
+      dpv = pair_dot<T, DH>(do_row, vr, h, act);
+    }
     if constexpr (DROP) dpv = drop_keep(drop, row_key, (uint32_t)(sh.S_text + p)) ? dpv * drop.inv_keep : 0.f;
     if (act) {
       const float pw = __expf(sc - lse);
-      axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
+      if constexpr (TOGETHER) kv.axpy_k(dq, pw * (dpv - delta) * sh.scale);
+      else axpy_rowvec<T, DH>(dq, pw * (dpv - delta) * sh.scale, kr, h, true);
     }
   }
 

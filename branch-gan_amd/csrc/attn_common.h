@@ -344,6 +344,128 @@ __device__ __forceinline__ float pair_dot(const T* a, const T* b, int h, bool va
   return acc + __shfl_xor(acc, 32);
 }
 
+// This lane's key / value rows of slot `slot` (nullptr for lanes that are not `act`, or whose slot is out of range).  The
+// pointer tables are kernel arguments: they are read with SCALAR loads, once per distinct slot among the wave's active lanes
+// (one, when a query tile lies inside a node) - indexed per lane they were a vector load from the argument buffer, one more
+// dependent round trip between the path entry and the key row.
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const void*)(((uint64_t)hi << 32) | lo);
+}
+
+template <typename T>
+__device__ __forceinline__ void slot_rows(const AttnArgs& a, int slot, bool act, int64_t off, const T*& kr, const T*& vr) {
+  kr = nullptr;
+  vr = nullptr;
+  unsigned long long todo = __ballot(act && slot >= 0 && slot < a.sh.n_slots);
+  while (todo) {
+    const int s = __builtin_amdgcn_readlane(slot, __builtin_ctzll(todo));
+    const T* kp = (const T*)uniform_ptr(a.k_slots[s]);   // (kept out of the branch below, where the index would be per lane again)
+    const T* vp = (const T*)uniform_ptr(a.v_slots[s]);
+    const bool mine = act && slot == s;
+    if (mine) { kr = kp + off; vr = vp + off; }
+    todo &= ~__ballot(mine);
+  }
+}
+
+// A branch key and its value (this lane's own rows of a slot) requested TOGETHER and held in registers: k in pair_dot's layout
+// (this half-wave's DH / 2 features, 16-byte pieces), v in axpy_rowvec's.  pair_dot on the key and axpy_rowvec on the value behind
+// the softmax update were two dependent round trips per path entry; dot() and axpy() add in the order of those two functions.
+template <typename T, int DH>
+struct PathRow {
+  static constexpr int VEC = 16 / sizeof(T);
+  typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x8>::type KV;
+  typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x4>::type VV;
+  KV k[DH / 2 / VEC];
+  VV v[DH / 8];
+  __device__ __forceinline__ void load(const T* kr, const T* vr, int h, bool valid) {
+#pragma unroll
+    for (int c = 0; c < DH / 2 / VEC; ++c)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) k[c][j] = (T)0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = (T)0.f;
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < DH / 2 / VEC; ++c) k[c] = *(const KV*)(kr + h * (DH / 2) + VEC * c);
+#pragma unroll
+      for (int i = 0; i < DH / 8; ++i) v[i] = *(const VV*)(vr + (i >> 2) * 32 + 8 * (i & 3) + 4 * h);
+    }
+  }
+  // a . k over the whole row (both half-waves): `a` is this lane's row, readable by every lane (LDS or global)
+  __device__ __forceinline__ float dot(const T* a, int h, bool valid) const {
+    float acc = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < DH / 2 / VEC; ++c) {
+        const KV x = *(const KV*)(a + h * (DH / 2) + VEC * c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc = fmaf((float)x[j], (float)k[c][j], acc);
+      }
+    }
+    return acc + __shfl_xor(acc, 32);
+  }
+  __device__ __forceinline__ void axpy(f32x16 (&acc)[DH / 32], float w) const {
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i >> 2][4 * (i & 3) + j] = fmaf(w, (float)v[i][j], acc[i >> 2][4 * (i & 3) + j]);
+  }
+};
+
+// The backward's form: key and value rows in pair_dot's layout (for q . k and dO . v) and the key row once more in
+// axpy_rowvec's (dQ += dS k), all requested in one round.
+template <typename T, int DH>
+struct BwdPathRow {
+  static constexpr int VEC = 16 / sizeof(T);
+  typedef typename PathRow<T, DH>::KV KV;
+  typedef typename PathRow<T, DH>::VV VV;
+  KV k[DH / 2 / VEC], v[DH / 2 / VEC];
+  VV k2[DH / 8];
+  __device__ __forceinline__ void load(const T* kr, const T* vr, int h, bool valid) {
+#pragma unroll
+    for (int c = 0; c < DH / 2 / VEC; ++c)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { k[c][j] = (T)0.f; v[c][j] = (T)0.f; }
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k2[i][j] = (T)0.f;
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < DH / 2 / VEC; ++c) {
+        k[c] = *(const KV*)(kr + h * (DH / 2) + VEC * c);
+        v[c] = *(const KV*)(vr + h * (DH / 2) + VEC * c);
+      }
+#pragma unroll
+      for (int i = 0; i < DH / 8; ++i) k2[i] = *(const VV*)(kr + (i >> 2) * 32 + 8 * (i & 3) + 4 * h);
+    }
+  }
+  __device__ __forceinline__ float dot(const KV (&y)[DH / 2 / VEC], const T* a, int h, bool valid) const {
+    float acc = 0.f;
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < DH / 2 / VEC; ++c) {
+        const KV x = *(const KV*)(a + h * (DH / 2) + VEC * c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc = fmaf((float)x[j], (float)y[c][j], acc);
+      }
+    }
+    return acc + __shfl_xor(acc, 32);
+  }
+  __device__ __forceinline__ float dot_k(const T* a, int h, bool valid) const { return dot(k, a, h, valid); }
+  __device__ __forceinline__ float dot_v(const T* a, int h, bool valid) const { return dot(v, a, h, valid); }
+  __device__ __forceinline__ void axpy_k(f32x16 (&acc)[DH / 32], float w) const {
+#pragma unroll
+    for (int i = 0; i < DH / 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i >> 2][4 * (i & 3) + j] = fmaf(w, (float)k2[i][j], acc[i >> 2][4 * (i & 3) + j]);
+  }
+};
+
 // acc[dt][reg] += w * row[d(dt, reg, h)] : adds a scaled DH-vector (this lane's own row in global memory)
 // to an accumulator set whose rows are d (the layout of out[] in mma_reduce_rows).
 template <typename T, int DH>

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   // ONE round of loads: context length, path, the Q tile and - before the number of key tiles is known - key tile `wave`
   int ctx = valid ? a.ctx_len[kq] : 0;
   const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
+  const int slot_first = wave < sh.max_path ? a.path[n * sh.max_path + wave] : 0;   // this wave's first path entry, in the same round
   T* q_l = (T*)(smem + SL::STAGE_BYTES);
   TileRegs<T, DH, 256> gq;
   gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, blk.x * ATT_TILE, tid);
@@ -286,15 +287,22 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   // branch keys, path entries wave, wave + 4, ...  (key-range split: the last split's)
   for (int p = (!KVSPLIT || split == n_splits - 1) ? wave : sh.max_path; p < sh.max_path; p += ATT_WAVES) {
     const bool act = p < plen;
-    const int slot = a.path[n * sh.max_path + p];          // in bounds for every p < max_path: no wait on path_len first
+    const int slot = p == wave ? slot_first : a.path[n * sh.max_path + p];   // in bounds for every p < max_path: no wait on path_len first
     const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
-    const T* kr = nullptr;
-    const T* vr = nullptr;
-    for (int sidx = 0; sidx < sh.n_slots; ++sidx) {
-      if (sidx == slot) { kr = (const T*)a.k_slots[sidx] + off; vr = (const T*)a.v_slots[sidx] + off; }
+    const T* kr;
+    const T* vr;
+    slot_rows<T>(a, slot, act, off, kr, vr);
+    // key and value rows in ONE round of loads where the registers allow (path -> key -> value was three round trips an entry)
+    constexpr bool TOGETHER = DH * sizeof(T) <= 256;
+    [[maybe_unused]] PathRow<T, TOGETHER ? DH : 32> kv;
+    float sc;
+    if constexpr (TOGETHER) {
+      kv.load(kr, vr, h, act && kr);
+      sc = kv.dot(q_row, h, act) * sh.scale;
+    } else {
+      sc = pair_dot<T, DH>(q_row, kr, h, act && kr) * sh.scale;
     }
-    const float sc = pair_dot<T, DH>(q_row, kr, h, act) * sh.scale;
-    if (act) {
+    if (act && kr) {
       const float m_new = fmaxf(m, sc);
       const float alpha = __expf(m - m_new);
       const float pw = __expf(sc - m_new);
@@ -306,7 +314,11 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       bool kept = true;
       if constexpr (DROP) kept = drop_keep(drop, row_key, (uint32_t)(sh.S_text + p));
-      if (kept) axpy_rowvec<T, DH>(o, pw, vr, h, true);
+      if constexpr (TOGETHER) {
+        if (kept) kv.axpy(o, pw);
+      } else {
+        if (kept) axpy_rowvec<T, DH>(o, pw, vr, h, true);
+      }
     }
   }
 
