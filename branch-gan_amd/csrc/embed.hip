@@ -73,13 +73,23 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_first_kernel(const int64_
   const int quarter = (((r_last + 4) >> 2) + 3) >> 2 << 2;            // int4 reads per wave, rounded up: 4 quarters cover [0, r_last]
   const int j_begin = wave * quarter, j_end = min(j_begin + quarter, (r_last + 4) & ~3);
   int f = r;
-  for (int j = j_begin; j < j_end; j += 4) {
-    const int4 v = *(const int4*)&s_idx[j];
+  auto fold = [&](const int4 v, int j) __attribute__((always_inline)) {
     if (v.w == mine && j + 3 < f) f = j + 3;
     if (v.z == mine && j + 2 < f) f = j + 2;
     if (v.y == mine && j + 1 < f) f = j + 1;
     if (v.x == mine && j < f) f = j;
+  };
+  // four LDS reads in flight per lane (one read per iteration left the scan waiting out the LDS latency 192 times at 3072 rows);
+  // f is a minimum over matches, so the order of the folds does not matter
+  int j = j_begin;
+  for (; j + 16 <= j_end; j += 16) {
+    const int4 v0 = *(const int4*)&s_idx[j], v1 = *(const int4*)&s_idx[j + 4], v2 = *(const int4*)&s_idx[j + 8], v3 = *(const int4*)&s_idx[j + 12];
+    fold(v0, j);
+    fold(v1, j + 4);
+    fold(v2, j + 8);
+    fold(v3, j + 12);
   }
+  for (; j < j_end; j += 4) fold(*(const int4*)&s_idx[j], j);
   s_min[wave][lane] = f;
   __syncthreads();
   if (wave == 0 && r < n) first[r] = min(min(s_min[0][lane], s_min[1][lane]), min(s_min[2][lane], s_min[3][lane]));
@@ -97,7 +107,6 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_accum_kernel(const float*
   const int64_t t = idx[(base + r) % idx_rows];
   if (t < 0 || t >= table_rows) return;                 // the forward poisoned these rows; there is nothing to add them to
   __shared__ int s_list[EMBED_CHUNK];
-  __shared__ int s_wave_count[4];
   __shared__ int s_total;
   __shared__ __align__(16) float s_part[3][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,21 +134,42 @@ __global__ __launch_bounds__(EMBED_THREADS) void embed_accum_kernel(const float*
     }
     return;
   }
-  // ordered compaction into s_list
-  if (threadIdx.x == 0) s_total = 0;
-  __syncthreads();
-  for (int k = 0; j_begin + k * EMBED_THREADS < n; ++k) {
-    const bool hit = (hits >> k) & 1u;
-    const uint64_t m = __ballot(hit);
-    if (lane == 0) s_wave_count[wave] = __popcll(m);
-    __syncthreads();
-    int off = s_total;
-    for (int w = 0; w < wave; ++w) off += s_wave_count[w];
-    if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1))] = j_begin + k * EMBED_THREADS + threadIdx.x;
-    __syncthreads();
-    if (threadIdx.x == 0) s_total += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-    __syncthreads();
+  // ordered compaction into s_list: the hits of slot k, wave w are counted by a ballot (no barrier), the counts meet in LDS,
+  // and every wave adds up what lies before each of its slots - two barriers, where a running total per slot took three each
+  __shared__ int s_count[EMBED_SLOTS][4];
+  static_assert(EMBED_SLOTS <= 64, "one lane per slot");
+  {
+    int count_k = 0;                                     // lane k keeps this wave's count of slot k (0 for slots past the chunk's end)
+#pragma unroll
+    for (int k = 0; k < EMBED_SLOTS; ++k) {
+      const int c = __popcll(__ballot((hits >> k) & 1u));
+      if (lane == k) count_k = c;
+    }
+    if (lane < EMBED_SLOTS) s_count[lane][wave] = count_k;
   }
+  __syncthreads();
+  {
+    // lane k of every wave: entries before (slot k, this wave) = all waves of the slots below k + the lower waves of slot k
+    int mine_k = 0, row_k = 0;
+    if (lane < EMBED_SLOTS) {
+      for (int w = 0; w < 4; ++w) { const int c = s_count[lane][w]; row_k += c; if (w < wave) mine_k += c; }
+    }
+    int below = row_k;                                   // exclusive prefix of the slot totals over the lanes
+#pragma unroll
+    for (int d = 1; d < EMBED_SLOTS; d <<= 1) { const int o = __shfl_up(below, d); if (lane >= d) below += o; }
+    const int total_all = __shfl(below, EMBED_SLOTS - 1);
+    below -= row_k;
+    const int start = below + mine_k;
+#pragma unroll
+    for (int k = 0; k < EMBED_SLOTS; ++k) {
+      const int off = __shfl(start, k);
+      const bool hit = (hits >> k) & 1u;
+      const uint64_t m = __ballot(hit);
+      if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1))] = j_begin + k * EMBED_THREADS + threadIdx.x;
+    }
+    if (threadIdx.x == 0) s_total = total_all;
+  }
+  __syncthreads();
   const int total = s_total;
   // wave w sums list entries w, w + 4, ... in ascending order; its lanes span 256 columns
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
