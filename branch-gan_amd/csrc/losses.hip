@@ -19,7 +19,7 @@ __device__ __forceinline__ float bce(float x, float y) { return -(y * clog(x) + 
 // ATen binary_cross_entropy_backward: (x - y) / max((1 - x) * x, 1e-12)
 __device__ __forceinline__ float bce_grad(float x, float y) { return (x - y) / fmaxf((1.f - x) * x, 1e-12f); }
 
-template <int NV>
+template <int NV, int THREADS = LOSS_THREADS>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV][16] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -31,7 +31,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* sh /* [NV][16] 
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     float t = 0.f;
-    for (int w = 0; w < LOSS_THREADS / 64; ++w) t += sh[i * 16 + w];
+    for (int w = 0; w < THREADS / 64; ++w) t += sh[i * 16 + w];
     v[i] = t;
   }
   __syncthreads();
@@ -211,11 +211,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_loss_kernel(RlArgs a) {
 // (score 0, probability 1e-5) and are NOT weighted by the depth mask, except in the three zone factors.
 // A zone whose mask is empty reports 0 (the reference's `if x.sum() > 0 else 0`).
 constexpr int RL_DIAG_ACC = 26;
+// 512 threads, not the loss kernels' 1024: 26 accumulators beside four elements' operands in flight do not fit the 128 registers
+// a lane has at 1024 (310 of them spilled, 1.2 KB of scratch per lane: 82 us at configs[1], four times the loss kernel's time)
+constexpr int RL_DIAG_THREADS = 512;
 
 // One workgroup, a few KB of input: the kernel's time is its dependent global round trips, so every loop below takes its
 // elements U at a time with all their loads issued before the first use (8 rounds of loads -> 3: 87 -> ~20 us at configs[1]).
 // The padded columns j >= K of the alteration rows do not depend on the node: once per (b, j), weighted by N.
-__global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
+__global__ __launch_bounds__(RL_DIAG_THREADS) void rl_diag_kernel(RlArgs a) {
   __shared__ float red[RL_DIAG_ACC * 16];
   const bg_rl_loss_shape& s = a.sh;
   const int tid = threadIdx.x;
@@ -238,11 +241,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
   };
   // ---- the input row: (b, t) over B x S -------------------------------------------------------------------------------------
   const int n_in_el = s.B * s.S;
-  for (int i0 = tid; i0 < n_in_el; i0 += U * LOSS_THREADS) {
+  for (int i0 = tid; i0 < n_in_el; i0 += U * RL_DIAG_THREADS) {
     float in_h[U], alt_h[U], score[U], own[U], lp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u * LOSS_THREADS, n_in_el - 1);
+      const int i = min(i0 + u * RL_DIAG_THREADS, n_in_el - 1);
       const int b = i / s.S, t = i % s.S;
       in_h[u] = a.in_head[i]; alt_h[u] = a.alt_head[i]; own[u] = a.in[i];
       score[u] = a.in[min(i + 1, n_in_el - 1)];
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * LOSS_THREADS;
+      const int i = i0 + u * RL_DIAG_THREADS;
       if (i >= n_in_el) break;
       const int t = i % s.S;
       const float sc = t + 1 < s.S ? score[u] : 0.f;
@@ -272,11 +275,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
   }
   // ---- the alteration rows, real columns: (b, n, j < K) --------------------------------------------------------------------------
   const int n_real = s.B * s.N * s.K;
-  for (int i0 = tid; i0 < n_real; i0 += U * LOSS_THREADS) {
+  for (int i0 = tid; i0 < n_real; i0 += U * RL_DIAG_THREADS) {
     float in_h[U], alt_h[U], score[U], lp[U], m[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int e = min(i0 + u * LOSS_THREADS, n_real - 1);
+      const int e = min(i0 + u * RL_DIAG_THREADS, n_real - 1);
       const int j = e % s.K, n = (e / s.K) % s.N, b = e / (s.K * s.N);
       score[u] = a.alt[e]; lp[u] = a.alt_lp[e];
       in_h[u] = a.in_head[b * s.S + j]; alt_h[u] = a.alt_head[b * s.S + j];
@@ -284,28 +287,28 @@ __global__ __launch_bounds__(LOSS_THREADS) void rl_diag_kernel(RlArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (i0 + u * LOSS_THREADS < n_real) add_alt(score[u], in_h[u], alt_h[u], true, lp[u], m[u], 1.f);
+      if (i0 + u * RL_DIAG_THREADS < n_real) add_alt(score[u], in_h[u], alt_h[u], true, lp[u], m[u], 1.f);
   }
   // ---- their padded columns (score 0, probability 1e-5, outside the depth mask): (b, K <= j < S), the same for every node ----------
   const int pad = s.S - s.K, n_pad = s.B * pad;
-  for (int i0 = tid; i0 < n_pad; i0 += U * LOSS_THREADS) {
+  for (int i0 = tid; i0 < n_pad; i0 += U * RL_DIAG_THREADS) {
     float in_h[U], alt_h[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u * LOSS_THREADS, n_pad - 1);
+      const int i = min(i0 + u * RL_DIAG_THREADS, n_pad - 1);
       const int b = i / pad, j = s.K + i % pad;
       in_h[u] = a.in_head[b * s.S + j]; alt_h[u] = a.alt_head[b * s.S + j];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (i0 + u * LOSS_THREADS < n_pad) add_alt(0.f, in_h[u], alt_h[u], false, 0.f, 0.f, (float)s.N);
+      if (i0 + u * RL_DIAG_THREADS < n_pad) add_alt(0.f, in_h[u], alt_h[u], false, 0.f, 0.f, (float)s.N);
   }
   float mask_sum = 0.f;
   if (s.use_depth_mask)
-    for (int i = tid; i < s.N * s.K; i += LOSS_THREADS) mask_sum += a.mask[i];
-  block_sum<RL_DIAG_ACC>(acc, red);
+    for (int i = tid; i < s.N * s.K; i += RL_DIAG_THREADS) mask_sum += a.mask[i];
+  block_sum<RL_DIAG_ACC, RL_DIAG_THREADS>(acc, red);
   float one[1] = {mask_sum};
-  block_sum<1>(one, red);
+  block_sum<1, RL_DIAG_THREADS>(one, red);
   if (tid == 0) {
     const float n_in = (float)s.B * s.S, n_alt = (float)s.B * s.N * s.S;
     auto ratio = [](float num, float den) { return den > 0.f ? num / den : 0.f; };
@@ -452,7 +455,7 @@ extern "C" int bg_rl_loss_fwd(const bg_rl_loss_shape* shape, const float* input_
   hipLaunchKernelGGL(rl_loss_kernel<false>, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
   BG_CHECK_LAUNCH("bg_rl_loss_fwd");
   if (out_diag) {
-    hipLaunchKernelGGL(rl_diag_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rl_diag_kernel, dim3(1), dim3(RL_DIAG_THREADS), 0, (hipStream_t)stream, a);
     BG_CHECK_LAUNCH("bg_rl_loss_fwd (diagnostics)");
   }
   return BG_OK;
