@@ -152,6 +152,21 @@ __global__ __launch_bounds__(256) void branch_attn_fwd_kernel(AttnArgs a) {
 // w, w+4, ..., each with a private K/V staging area in LDS (no workgroup barrier inside the loop, next tile's global
 // loads in flight behind the current tile's MFMAs), and the four partial (max, sum, O) states are merged through LDS at
 // the end.  grid.x = number of 32-query tiles: 4x the workgroups and a 4x shorter chain per wave.
+// BG_ATTN_TRACE (the diagnostic library of `make trace`, benchmarks/probes/attn_fwd_trace.py): every wave of the key-split forward
+// leaves wall-clock stamps (100 MHz) at its phase boundaries, with a full s_waitcnt before each.
+#ifdef BG_ATTN_TRACE
+#define BG_FTRACE_WAVES 8192
+__device__ unsigned long long g_attn_fwd_trace[BG_FTRACE_WAVES][16];
+#define BG_FTRACE(slot)                                                                            \
+  do {                                                                                             \
+    __builtin_amdgcn_s_waitcnt(0);                                                                 \
+    const unsigned w_ = (blockIdx.x + blockIdx.y * gridDim.x) * ATT_WAVES + (threadIdx.x >> 6);    \
+    if ((threadIdx.x & 63) == 0 && w_ < BG_FTRACE_WAVES) g_attn_fwd_trace[w_][slot] = wall_clock64(); \
+  } while (0)
+#else
+#define BG_FTRACE(slot)
+#endif
+
 template <typename T, int DH> struct SplitLds {
   using L = Lds<T, DH>;
   static constexpr int K_ELEMS = L::ROW_ELEMS;
@@ -162,7 +177,10 @@ template <typename T, int DH> struct SplitLds {
   // the workgroup's own Q tile, fetched once by all 256 threads in whole 16-byte row chunks (as in attn_bwd_split.hip: a lane
   // that reads its own row from global memory touches 32 cache lines per load instruction, and four waves did it four times)
   static constexpr size_t Q_BYTES = ((size_t)L::ROW_ELEMS * sizeof(T) + 15) / 16 * 16;
-  static constexpr size_t BYTES = STAGE_BYTES + Q_BYTES + 64;
+  // the slot pointer tables (kernel arguments) copied once, by lane, in the prologue's round of loads: a path entry's rows are
+  // then one LDS read away from their address (read from the argument buffer they were one more round trip behind the entry)
+  static constexpr size_t PTR_OFF = STAGE_BYTES + Q_BYTES + 64;
+  static constexpr size_t BYTES = PTR_OFF + 2 * BG_MAX_SLOTS * sizeof(void*);
 };
 
 //
@@ -178,13 +196,17 @@ template <int DH> constexpr size_t fwd_part_floats() { return (size_t)(DH + 2) *
 
 // DROP: dropout on the attention probabilities (attn_dropout.h) - the sum l runs over the undropped weights, the products with V
 // over the kept ones, the output is scaled by 1 / (1 - p) at the end.
-template <typename T, int DH, bool KVSPLIT = false, bool DROP = false>
-__global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_attn_fwd_split_kernel(AttnArgs a) {
+// PF: the key / value rows of a wave's first two path entries are requested BEFORE the text tiles and arrive behind them (64
+// more registers at Dh 64: two waves per SIMD, not three - taken for launches of at most two workgroups per CU, where the third
+// would not exist anyway).  Without PF they are requested together behind the tiles.
+template <typename T, int DH, bool KVSPLIT = false, bool DROP = false, bool PF = false>
+__global__ __launch_bounds__(256, (PF ? (DH * sizeof(T) <= 128 ? 2 : 1) : (DH * sizeof(T) <= 128 ? 3 : 1))) void branch_attn_fwd_split_kernel(AttnArgs a) {
   using SL = SplitLds<T, DH>;
   constexpr int NDT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bg_attn_shape& sh = a.sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  BG_FTRACE(0);
   T* k_row = (T*)(smem + wave * SL::WAVE_BYTES);
   T* v_z = k_row + SL::K_ELEMS;
   BlockXY blk = xcd_block();
@@ -210,7 +232,9 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   // ONE round of loads: context length, path, the Q tile and - before the number of key tiles is known - key tile `wave`
   int ctx = valid ? a.ctx_len[kq] : 0;
   const int plen = (valid && sh.max_path) ? a.path_len[n] : 0;   // path tables may be NULL when max_path == 0
-  const int slot_first = wave < sh.max_path ? a.path[n * sh.max_path + wave] : 0;   // this wave's first path entry, in the same round
+  // this wave's first two path entries (p = wave, wave + 4), in the same round
+  const int slot_first = wave < sh.max_path ? a.path[n * sh.max_path + wave] : 0;
+  const int slot_second = wave + ATT_WAVES < sh.max_path ? a.path[n * sh.max_path + wave + ATT_WAVES] : 0;
   T* q_l = (T*)(smem + SL::STAGE_BYTES);
   TileRegs<T, DH, 256> gq;
   gq.load_nk((const T*)a.q + (int64_t)b * sh.q_sb + (int64_t)hh * sh.q_sh, sh.q_sn, sh.q_sk, sh.K, R, blk.x * ATT_TILE, tid);
@@ -218,6 +242,12 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
   if ((t_lo + wave) * ATT_TILE < sh.S_text) {
     kreg.load(kt, sh.t_ss, (t_lo + wave) * ATT_TILE, sh.S_text, lane);
     vreg.load(vt, sh.t_ss, (t_lo + wave) * ATT_TILE, sh.S_text, lane);
+  }
+  BG_FTRACE(1);   // the prologue's loads are in
+  const void** ptr_l = (const void**)(smem + SL::PTR_OFF);
+  if (tid < sh.n_slots) {
+    ptr_l[tid] = a.k_slots[tid];
+    ptr_l[BG_MAX_SLOTS + tid] = a.v_slots[tid];
   }
   gq.template store<true, false>(q_l, nullptr, tid);
   __syncthreads();
@@ -230,6 +260,38 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tile_ctx = max(tile_ctx, __shfl_xor(tile_ctx, o));
   const int ntiles = min((tile_ctx + ATT_TILE - 1) / ATT_TILE, KVSPLIT ? t_lo + t_per : (1 << 28));
+
+  BG_FTRACE(2);   // Q staged, barrier, reach
+  // key and value rows of an entry in ONE round of loads where the registers allow (path -> pointer -> key -> value was four
+  // round trips an entry), the first two entries of the wave in the SAME round (path tables up to 8 entries: all of them)
+  constexpr bool TOGETHER = DH * sizeof(T) <= 256;
+  constexpr int NPRE = TOGETHER ? 2 : 0;
+  const bool path_here = !KVSPLIT || split == n_splits - 1;          // key-range split: the branch keys ride with the last split
+  const int64_t slot_off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
+  [[maybe_unused]] PathRow<T, TOGETHER ? DH : 32> kvp[2];
+  [[maybe_unused]] bool actp[2] = {false, false};
+  auto rows_of = [&](int slot, bool act, const T*& kr, const T*& vr) __attribute__((always_inline)) {
+    kr = nullptr;
+    vr = nullptr;
+    if (act && slot >= 0 && slot < sh.n_slots) {
+      kr = (const T*)ptr_l[slot] + slot_off;
+      vr = (const T*)ptr_l[BG_MAX_SLOTS + slot] + slot_off;
+    }
+  };
+  auto preload = [&]() __attribute__((always_inline)) {
+    if constexpr (NPRE > 0) {
+#pragma unroll
+      for (int e = 0; e < NPRE; ++e) {
+        const int p = wave + e * ATT_WAVES;
+        const T* kr;
+        const T* vr;
+        rows_of(e == 0 ? slot_first : slot_second, path_here && p < plen, kr, vr);
+        actp[e] = path_here && p < plen && kr;
+        kvp[e].load(kr, vr, h, actp[e]);
+      }
+    }
+  };
+  if constexpr (PF) preload();
 
   float m = -INFINITY, l = 0.f;
   f32x16 o[NDT];
@@ -284,25 +346,10 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     else mma_reduce_rows_tr<DH, 0, NDT>(o, s, v_z, lane);
   }
 
+  BG_FTRACE(3);   // text tiles
   // branch keys, path entries wave, wave + 4, ...  (key-range split: the last split's)
-  for (int p = (!KVSPLIT || split == n_splits - 1) ? wave : sh.max_path; p < sh.max_path; p += ATT_WAVES) {
-    const bool act = p < plen;
-    const int slot = p == wave ? slot_first : a.path[n * sh.max_path + p];   // in bounds for every p < max_path: no wait on path_len first
-    const int64_t off = (int64_t)b * sh.s_sb + (int64_t)hh * sh.s_sh + (int64_t)kq * sh.s_sk;
-    const T* kr;
-    const T* vr;
-    slot_rows<T>(a, slot, act, off, kr, vr);
-    // key and value rows in ONE round of loads where the registers allow (path -> key -> value was three round trips an entry)
-    constexpr bool TOGETHER = DH * sizeof(T) <= 256;
-    [[maybe_unused]] PathRow<T, TOGETHER ? DH : 32> kv;
-    float sc;
-    if constexpr (TOGETHER) {
-      kv.load(kr, vr, h, act && kr);
-      sc = kv.dot(q_row, h, act) * sh.scale;
-    } else {
-      sc = pair_dot<T, DH>(q_row, kr, h, act && kr) * sh.scale;
-    }
-    if (act && kr) {
+  auto entry = [&](float sc, bool act, int p, auto&& add_value) __attribute__((always_inline)) {
+    if (act) {
       const float m_new = fmaxf(m, sc);
       const float alpha = __expf(m - m_new);
       const float pw = __expf(sc - m_new);
@@ -314,14 +361,34 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       bool kept = true;
       if constexpr (DROP) kept = drop_keep(drop, row_key, (uint32_t)(sh.S_text + p));
-      if constexpr (TOGETHER) {
-        if (kept) kv.axpy(o, pw);
-      } else {
-        if (kept) axpy_rowvec<T, DH>(o, pw, vr, h, true);
-      }
+      if (kept) add_value(pw);
+    }
+  };
+  if constexpr (!PF) preload();
+  if constexpr (NPRE > 0) {
+#pragma unroll
+    for (int e = 0; e < NPRE; ++e) {
+      const int p = wave + e * ATT_WAVES;
+      if (p < sh.max_path && path_here)                    // wave-uniform
+        entry(kvp[e].dot(q_row, h, actp[e]) * sh.scale, actp[e], p, [&](float pw) { kvp[e].axpy(o, pw); });
+    }
+  }
+  for (int p = path_here ? wave + NPRE * ATT_WAVES : sh.max_path; p < sh.max_path; p += ATT_WAVES) {
+    const int slot = a.path[n * sh.max_path + p];          // in bounds for every p < max_path: no wait on path_len first
+    const T* kr;
+    const T* vr;
+    rows_of(slot, p < plen, kr, vr);
+    const bool act = p < plen && kr;
+    if constexpr (TOGETHER) {
+      PathRow<T, TOGETHER ? DH : 32> kv;
+      kv.load(kr, vr, h, act);
+      entry(kv.dot(q_row, h, act) * sh.scale, act, p, [&](float pw) { kv.axpy(o, pw); });
+    } else {
+      entry(pair_dot<T, DH>(q_row, kr, h, act) * sh.scale, act, p, [&](float pw) { axpy_rowvec<T, DH>(o, pw, vr, h, true); });
     }
   }
 
+  BG_FTRACE(4);   // branch keys
   // merge the four waves' states:  mo[wave][d][query], ml[wave][{m, l}][query]
   __syncthreads();
   float* mo = (float*)smem;
@@ -336,6 +403,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
     ml[(wave * 2 + 1) * ATT_TILE + qcol] = l;
   }
   __syncthreads();
+  BG_FTRACE(5);   // states in LDS, barrier
   // thread -> query tid & 31, feature group tid >> 5 (8 groups of DH / 8 consecutive features)
   {
     constexpr int PER = DH / 8;
@@ -399,6 +467,7 @@ __global__ __launch_bounds__(256, (DH * sizeof(T) <= 128 ? 3 : 1)) void branch_a
       if (grp == 0) a.lse[((int64_t)bh * sh.NQ + n2) * sh.K + k2] = (lstar > 0.f) ? mstar + logf(lstar) : -INFINITY;
     }
   }
+  BG_FTRACE(6);   // stored
 }
 
 // The splits of a query tile combined: thread -> query tid & 31, feature group tid >> 5, as in the epilogue above.
@@ -513,6 +582,16 @@ static void launch_fwd_split(const AttnArgs& a, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((branch_attn_fwd_merge_kernel<T, DH>), grid, dim3(256), 0, st, a);
     return;
   }
+  // at most two workgroups per CU and branch keys to fetch: their rows are requested before the text tiles (PF)
+  static const bool pf_on = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_PF"); return !(e && e[0] == '0'); }();   // A/B runs
+  if constexpr (sizeof(T) == 2 && DH <= 128) {
+    if (pf_on && a.sh.max_path > 0 && (int64_t)grid.x * grid.y <= 512) {
+      auto kernel = branch_attn_fwd_split_kernel<T, DH, false, false, true>;
+      set_lds_limit(kernel, lds);
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+      return;
+    }
+  }
   auto kernel = branch_attn_fwd_split_kernel<T, DH, false>;
   set_lds_limit(kernel, lds);
   hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
@@ -558,6 +637,12 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st) {
 }  // namespace bg
 
 using namespace bg;
+
+#ifdef BG_ATTN_TRACE
+extern "C" int bg_debug_attn_fwd_trace(unsigned long long* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bg::g_attn_fwd_trace), bytes < sizeof(bg::g_attn_fwd_trace) ? bytes : sizeof(bg::g_attn_fwd_trace));
+}
+#endif
 
 extern "C" size_t bg_branch_attn_fwd_workspace_bytes(const bg_attn_shape* shape) {
   if (!shape || validate_attn_shape(shape, "bg_branch_attn_fwd_workspace_bytes")) return 0;
