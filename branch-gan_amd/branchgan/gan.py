@@ -75,11 +75,11 @@ class GannSetup(torch.nn.Module):
                                                  clearTreePast=False)
         forwardData['DiscValueHeads'] = {
             'txtInputPreds': root.valueHeadData['InputValue'], 'txtAlterationsPreds': root.valueHeadData['AlterationsValue'],
-            'altInputPreds': torch.stack([n.valueHeadData['InputValue'] for n in nodes], dim=0),
-            'altAlterationsPreds': torch.stack([n.valueHeadData['AlterationsValue'] for n in nodes], dim=0)}
+            'altInputPreds': MultiStepPrediction.restack([n.valueHeadData['InputValue'] for n in nodes], 0),
+            'altAlterationsPreds': MultiStepPrediction.restack([n.valueHeadData['AlterationsValue'] for n in nodes], 0)}
         forwardData['SubNodeStructure'] = MultiStepPrediction.getSubNodeListTreeStructure(root, nodes)
         discInputPred = root.discPreds
-        discAlterationScores = torch.stack([n.discPreds.prediction for n in nodes], dim=1)       # (B, N, K)
+        discAlterationScores = MultiStepPrediction.restack([n.discPreds.prediction for n in nodes], 1)   # (B, N, K)
         MultiStepPrediction.clearTree(root, clearAll=True)
         return inputIDs, (firstPred.logits, probs, firstMaskedProbs), (discInputPred, discAlterationScores, depthMask, None), forwardData
 

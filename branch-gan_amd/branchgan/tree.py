@@ -428,6 +428,25 @@ def discRootForward(discriminator, ids, dualValueHeads=False):
     return out, inV, altV
 
 
+def part_of(whole, dim, i):
+    """whole.select(dim, i), tagged with where it came from (see restack)."""
+    part = whole.select(dim, i)
+    part._bg_part_of = (whole, dim, i)
+    return part
+
+
+def restack(parts, dim):
+    """torch.stack(parts, dim) - or, when the parts are slices 0 .. n-1 (in order) of one tensor along one dimension (part_of),
+    that tensor itself with the dimension moved to `dim`: the same values without the copy, and a backward that hands the
+    gradient to the whole instead of a zeros + copy + add per slice."""
+    tags = [getattr(p, '_bg_part_of', None) for p in parts]
+    if parts and all(t is not None for t in tags):
+        whole, d = tags[0][0], tags[0][1]
+        if whole.shape[d] == len(parts) and all(t[0] is whole and t[1] == d and t[2] == i for i, t in enumerate(tags)):
+            return whole.movedim(d, dim)
+    return torch.stack(parts, dim=dim)
+
+
 def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePast=True, clearFullTree=False,
                          dualValueHeads=False, rootPass=None):
     """MultiStepPrediction.py:335-366.  On the fused block path ONE forward over text + every branch node; otherwise TWO: the
@@ -455,10 +474,13 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
         tree_args = (K, N, paths, all_ids, pos, ctx_len_of(sparseIndex, device))
 
     def node_outputs(pred, inV, altV, kv, K, N):
+        inV4, altV4 = (inV.view(B, N, K, 1), altV.view(B, N, K, 1)) if dualValueHeads else (None, None)
         for i, n in enumerate(nodes):
-            vh = {'InputValue': inV.view(B, N, K, 1)[:, i], 'AlterationsValue': altV.view(B, N, K, 1)[:, i]} if dualValueHeads else None
+            # every per-node piece remembers the whole it is a slice of (part_of): a caller that stacks the pieces of ALL nodes
+            # again (GanSetup's loss inputs) takes the whole instead - no cat, and no zeros + copy + add per node in backward
+            vh = {'InputValue': part_of(inV4, 1, i), 'AlterationsValue': part_of(altV4, 1, i)} if dualValueHeads else None
             node_kv = [(k.unflatten(2, (N, K))[:, :, i], v.unflatten(2, (N, K))[:, :, i]) for k, v in kv]
-            n.addDiscPredictionToNode(DiscriminatorOutput(pred[:, i]), node_kv, None, vh)
+            n.addDiscPredictionToNode(DiscriminatorOutput(part_of(pred, 1, i)), node_kv, None, vh)
 
     lm = getattr(discriminator, 'nonResidualModel', None)
     if tree_args is not None and rootPass is None and lm is not None and lm.supportsMergedTree(ids) and \
