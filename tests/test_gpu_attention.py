@@ -69,6 +69,7 @@ CASES = [  # B, H, Dh, S, K, depth
     (2, 3, 64, 256, 32, 4), (1, 2, 128, 130, 40, 2), (2, 2, 32, 70, 33, 3), (1, 1, 256, 96, 64, 2), (1, 12, 64, 512, 64, 8),
     (2, 2, 256, 300, 48, 3),        # Dh 256 over ten key tiles with a ragged last one: in bf16 the key-split forward (round 2)
     (1, 4, 256, 512, 64, 4),        # c4's branch step: 8 workgroups x 16 key tiles - the key range split over 4 workgroups (round 3)
+    (1, 2, 64, 64, 8, 11),          # a path of 11 entries: three per wave - the two preloaded with the prologue and one behind them
 ]
 
 
