@@ -116,3 +116,24 @@ def test_worker_batch_size_split():
     from branchgan.training import worker_batch_size
     assert [worker_batch_size(8, 3, r) for r in range(3)] == [3, 3, 2]
     assert [worker_batch_size(64, 8, r) for r in range(8)] == [8] * 8
+
+
+def test_restack_of_all_slices_is_the_whole_and_anything_else_a_stack():
+    """tree.part_of / tree.restack: the slices 0 .. N-1 of one tensor, in order, restack to that tensor (a
+    view: same values, gradient handed over in one piece); a subset, another order or an untagged piece fall back to torch.stack."""
+    from branchgan import tree as T
+    whole = torch.randn(2, 4, 3, requires_grad=True)
+    parts = [T.part_of(whole, 1, i) for i in range(4)]
+    for dim in (0, 1, 2):
+        got, ref = T.restack(parts, dim), torch.stack([whole[:, i] for i in range(4)], dim=dim)
+        assert torch.equal(got, ref)
+        assert got._base is whole or got is whole                       # no copy was made
+    w = torch.randn(4, 2, 3)
+    g_view, = torch.autograd.grad((T.restack(parts, 0) * w).sum(), whole)
+    g_ref, = torch.autograd.grad((torch.stack([whole[:, i] for i in range(4)], dim=0) * w).sum(), whole)
+    assert torch.equal(g_view, g_ref)
+    for other in (parts[:3], parts[::-1], parts[:3] + [whole[:, 3]], [T.part_of(whole, 1, i) for i in (0, 1, 2, 2)]):
+        got = T.restack(other, 1)
+        assert got._base is None and torch.equal(got, torch.stack(list(other), dim=1))
+    two = [T.part_of(whole, 1, 0), T.part_of(whole.detach().clone(), 1, 1)] + parts[2:]
+    assert T.restack(two, 1)._base is None                              # slices of different tensors
