@@ -197,7 +197,7 @@ template <int DH> constexpr size_t fwd_part_floats() { return (size_t)(DH + 2) *
 // DROP: dropout on the attention probabilities (attn_dropout.h) - the sum l runs over the undropped weights, the products with V
 // over the kept ones, the output is scaled by 1 / (1 - p) at the end.
 // PF: the key / value rows of a wave's first two path entries are requested BEFORE the text tiles and arrive behind them (64
-// more registers at Dh 64: two waves per SIMD, not three - taken for launches of at most two workgroups per CU, where the third
+// more registers at Dh 64: two waves per SIMD, not three - taken for launches of at most one workgroup per CU, where the others
 // would not exist anyway).  Without PF they are requested together behind the tiles.
 template <typename T, int DH, bool KVSPLIT = false, bool DROP = false, bool PF = false>
 __global__ __launch_bounds__(256, (PF ? (DH * sizeof(T) <= 128 ? 2 : 1) : (DH * sizeof(T) <= 128 ? 3 : 1))) void branch_attn_fwd_split_kernel(AttnArgs a) {
@@ -584,10 +584,10 @@ static void launch_fwd_split(const AttnArgs& a, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((branch_attn_fwd_merge_kernel<T, DH>), grid, dim3(256), 0, st, a);
     return;
   }
-  // at most two workgroups per CU and branch keys to fetch: their rows are requested before the text tiles (PF)
+  // at most one workgroup per CU and branch keys to fetch: their rows are requested before the text tiles (PF)
   static const bool pf_on = [] { const char* e = getenv("BRANCHGAN_ATTN_FWD_PF"); return !(e && e[0] == '0'); }();   // A/B runs
   if constexpr (sizeof(T) == 2 && DH <= 128) {
-    if (pf_on && a.sh.max_path > 0 && (int64_t)grid.x * grid.y <= 512) {
+    if (pf_on && a.sh.max_path > 0 && (int64_t)grid.x * grid.y <= 256) {   // (257-512 workgroups, c2's tree passes: 11.9 vs 11.7 us)
       auto kernel = branch_attn_fwd_split_kernel<T, DH, false, false, true>;
       set_lds_limit(kernel, lds);
       hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
