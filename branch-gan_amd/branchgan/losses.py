@@ -30,6 +30,7 @@ def calcDiscriminatorLoss(gannSetup, inputScores, alterationScores, numNegativeU
     mask = discDepthMask.to(inputScores.device)[:, :K]
     out = ops.disc_losses(inputScores, alt, data['txtInputPreds'].squeeze(-1), data['txtAlterationsPreds'].squeeze(-1), altAlt,
                           mask, rootLinks, alterationLinks, numNegativeUpdateSamples)
+    out = out.unbind(0)       # (one unbind: its backward is one stack; out[i] five times was a zeros + copy + add per element)
     info = {'numAlterationSamples': min(numNegativeUpdateSamples, alt.shape[1]), 'ValueHeadLoss': out[4],
             'ValueHead-InputLoss': out[2].detach(), 'ValueHead-AltLoss': out[3].detach()}
     if collectTreeDepthData:
@@ -71,7 +72,7 @@ def reinforceLosses(labelLogProbs, alterationLogProbs, discInputScores, discAlte
     if debugStats is not None:
         out, diag = out
         debugStats.update(zip(ops.RL_DIAG_KEYS, diag.unbind(0)))
-    inputLoss, alterationLoss = out[0], out[1]
+    inputLoss, alterationLoss = out.unbind(0)
     N = discAlterationScores.shape[1]
     return {'input': inputLoss, 'alterations': alterationLoss, 'combined': (inputLoss + alterationLoss) / 2,
             'unweightedCombined': (inputLoss + alterationLoss) / (1 + N)}
