@@ -494,10 +494,13 @@ def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePas
                                      'use_cache': True}, doDiscForward=False, doTransformerPassWithPrediction=True)
         inV, altV = finish(None, out)
         kv = out.transformerPred.past_key_values
-        root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction[:, :S]), [(k[:, :, :S], v[:, :, :S]) for k, v in kv], None,
-                                     {'InputValue': inV[:, :S], 'AlterationsValue': altV[:, :S]} if dualValueHeads else None)
-        node_outputs(out.prediction[:, S:].reshape(B, N, K), inV[:, S:] if dualValueHeads else None,
-                     altV[:, S:] if dualValueHeads else None, [(k[:, :, S:], v[:, :, S:]) for k, v in kv], K, N)
+        # [text | tree] parts by ONE split per tensor: its backward is one cat, where two slices were a zeros + copy each and an add
+        cut = lambda t: t.split([S, t.shape[1] - S], dim=1)
+        pred_txt, pred_alt = cut(out.prediction)
+        (inV_txt, inV_alt), (altV_txt, altV_alt) = (cut(inV), cut(altV)) if dualValueHeads else ((None, None), (None, None))
+        root.addDiscPredictionToNode(DiscriminatorOutput(pred_txt), [(k[:, :, :S], v[:, :, :S]) for k, v in kv], None,
+                                     {'InputValue': inV_txt, 'AlterationsValue': altV_txt} if dualValueHeads else None)
+        node_outputs(pred_alt.reshape(B, N, K), inV_alt, altV_alt, [(k[:, :, S:], v[:, :, S:]) for k, v in kv], K, N)
     else:
         out, inV, altV = rootPass if rootPass is not None else discRootForward(discriminator, ids, dualValueHeads)
         root.addDiscPredictionToNode(DiscriminatorOutput(out.prediction), out.transformerPred.past_key_values, None,
