@@ -649,7 +649,10 @@ def link_tables(root_links, alt_links, device):
 
 
 def _f32c(t):
-    return t.contiguous().float()
+    """fp32 and contiguous in ONE copy (or none): .contiguous().float() was two launches for a strided bf16 tensor."""
+    if t.dtype == torch.float32:
+        return t.contiguous()
+    return t.to(torch.float32, memory_format=torch.contiguous_format)
 
 
 class _DiscLosses(torch.autograd.Function):
