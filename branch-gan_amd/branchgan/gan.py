@@ -68,7 +68,7 @@ class GannSetup(torch.nn.Module):
         K = nodes[0].ids.shape[1]
         depthMask = self.createDiscAlterationLossWeights(inputIDs, nodes, K)                     # (N, K)
         forwardData = {'TreeNodeInfo': [(n.depth, n.isRandom) for n in nodes]} if collectTreeDepthData else {}
-        forwardData['AlterationLogProbs'] = torch.stack([n.logProbs for n in nodes], dim=1)      # (B, N, K), autograd-connected
+        forwardData['AlterationLogProbs'] = MultiStepPrediction.restack([n.logProbs for n in nodes], 1)   # (B, N, K), autograd-connected
         forwardData['LabelLogProbs'] = root.labelLogProbs
         forwardData['NumBranchPoints'] = K
         MultiStepPrediction.multiStepDiscForward(self.discriminator, root, self.discriminatorDevice, dualValueHeads=True,

@@ -61,7 +61,7 @@ class PredictionTreeNode:
             beam = i if self.parent is None else self.beam
             self.children.append(PredictionTreeNode(ids[:, i], self, self.depth + 1, beam, None if probs is None else probs[:, :, i], isRandomSamples[i],
                                                     sparseIndex=self.sparseIndex, rootSeqSize=self.rootSeqSize,
-                                                    logProbs=None if logProbs is None else logProbs[:, :, i]))
+                                                    logProbs=None if logProbs is None else part_of(logProbs, 2, i)))
 
     def addDiscPredictionToNode(self, discPreds, past, attMask, valueHeadData=None):
         self.past, self.attMask, self.discPreds, self.valueHeadData = past, attMask, discPreds, valueHeadData
@@ -268,7 +268,7 @@ def _branch_step(generator, node, device, dropoutRate, numAlterations, strat, pa
 
 def _set_child_log_probs(node, lp):
     for j, child in enumerate(node.children):
-        child.logProbs = lp[:, :, j]
+        child.logProbs = part_of(lp, 2, j)               # (tagged: GanSetup stacks the nodes' log-probs again, see restack)
         child.probs = None                                  # lazily exp(logProbs)
 
 
@@ -327,7 +327,7 @@ def _attach_branch_gradients(generator, root, forwarded, device, pending=(), noi
     _, lp = ops.softmax_stats(out.prediction.logits, gather.view(B, N * K, n_max))
     lp = lp.view(B, N, K, n_max)
     for i, n in enumerate(forwarded):
-        _set_child_log_probs(n, lp[:, i])
+        _set_child_log_probs(n, part_of(lp, 1, i))
 
 
 def multiStepGenForward(generator, inputIDs, sampleRules, device, clearTreePast=True, clearFullTree=False, verbose=False,
@@ -429,22 +429,55 @@ def discRootForward(discriminator, ids, dualValueHeads=False):
 
 
 def part_of(whole, dim, i):
-    """whole.select(dim, i), tagged with where it came from (see restack)."""
+    """whole.select(dim, i), tagged with where it came from (see restack); `whole` may itself be such a part."""
     part = whole.select(dim, i)
     part._bg_part_of = (whole, dim, i)
     return part
 
 
+def _origin(t):
+    """(root tensor, {root dimension: index} picked on the way down to `t`) of a chain of part_of selections, else None."""
+    tag = getattr(t, '_bg_part_of', None)
+    if tag is None:
+        return None
+    chain = []
+    while tag is not None:
+        t, dim, i = tag
+        chain.append((dim, i))
+        tag = getattr(t, '_bg_part_of', None)
+    left, picked = list(range(t.dim())), {}
+    for dim, i in reversed(chain):                       # from the root outwards: `dim` counts the dimensions still there
+        picked[left.pop(dim)] = i
+    return t, picked
+
+
 def restack(parts, dim):
-    """torch.stack(parts, dim) - or, when the parts are slices 0 .. n-1 (in order) of one tensor along one dimension (part_of),
-    that tensor itself with the dimension moved to `dim`: the same values without the copy, and a backward that hands the
-    gradient to the whole instead of a zeros + copy + add per slice."""
-    tags = [getattr(p, '_bg_part_of', None) for p in parts]
-    if parts and all(t is not None for t in tags):
-        whole, d = tags[0][0], tags[0][1]
-        if whole.shape[d] == len(parts) and all(t[0] is whole and t[1] == d and t[2] == i for i, t in enumerate(tags)):
-            return whole.movedim(d, dim)
-    return torch.stack(parts, dim=dim)
+    """torch.stack(parts, dim) without copying what is already together.  Consecutive parts that are the slices 0 .. n-1 (in
+    order) of one tensor along one dimension (part_of, possibly nested: the other picked indices equal) are taken as that tensor
+    with the dimension moved to `dim`; the runs are joined by one cat.  One run: a view, no launch.  The values are torch.stack's;
+    the backward hands each run's gradient over in one piece instead of a zeros + copy + add per slice."""
+    origins = [_origin(p) for p in parts]
+    if not parts or any(o is None for o in origins):
+        return torch.stack(parts, dim=dim)
+    runs = []                                            # [root, picked dimensions, [(part, picked)]]
+    for p, (root, picked) in zip(parts, origins):
+        if runs and runs[-1][0] is root and runs[-1][1] == sorted(picked):
+            runs[-1][2].append((p, picked))
+        else:
+            runs.append([root, sorted(picked), [(p, picked)]])
+    pieces = []
+    for root, dims, members in runs:
+        varying = [d for d in dims if len({m[1][d] for m in members}) > 1]
+        if len(members) > 1 and len(varying) == 1 and [m[1][varying[0]] for m in members] == list(range(root.shape[varying[0]])):
+            v, t = varying[0], root
+            for d in sorted((d for d in dims if d != v), reverse=True):      # the constant picks, highest dimension first
+                t = t.select(d, members[0][1][d])
+            pieces.append(t.movedim(v - sum(1 for d in dims if d < v), dim))
+        elif len(members) == 1:
+            pieces.append(members[0][0].unsqueeze(dim))
+        else:
+            pieces.append(torch.stack([m[0] for m in members], dim=dim))
+    return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=dim)
 
 
 def multiStepDiscForward(discriminator, predictionTreeRoot, device, clearTreePast=True, clearFullTree=False,

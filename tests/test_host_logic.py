@@ -137,3 +137,24 @@ def test_restack_of_all_slices_is_the_whole_and_anything_else_a_stack():
         assert got._base is None and torch.equal(got, torch.stack(list(other), dim=1))
     two = [T.part_of(whole, 1, 0), T.part_of(whole.detach().clone(), 1, 1)] + parts[2:]
     assert T.restack(two, 1)._base is None                              # slices of different tensors
+
+
+def test_restack_joins_runs_of_nested_slices_with_one_cat():
+    """The generator's log-probs: node 1 is a slice of the root pass's (B, K, n) tensor, nodes 2 .. N slices of the tree pass's
+    (B, N, K, n) tensor picked twice (node, then child): restack takes the second run as one view and joins the runs by a cat."""
+    from branchgan import tree as T
+    a = torch.randn(2, 3, 1, requires_grad=True)                  # root level: (B, K, n_root)
+    t4 = torch.randn(2, 4, 3, 2, requires_grad=True)              # tree pass: (B, N, K, n_max)
+    parts = [T.part_of(a, 2, 0)] + [T.part_of(T.part_of(t4, 1, i), 2, 1) for i in range(4)]
+    ref = torch.stack([a[:, :, 0]] + [t4[:, i][:, :, 1] for i in range(4)], dim=1)
+    got = T.restack(parts, 1)
+    assert torch.equal(got, ref)
+    w = torch.randn_like(ref)
+    assert all(torch.equal(x, y) for x, y in zip(torch.autograd.grad((got * w).sum(), (a, t4)), torch.autograd.grad((ref * w).sum(), (a, t4))))
+    run = T.restack(parts[1:], 0)                                 # one run alone: a view of the tree pass's tensor
+    assert run._base is t4 and torch.equal(run, torch.stack([t4[:, i][:, :, 1] for i in range(4)], dim=0))
+    # children picked at different positions, or nodes out of order: plain stacks inside the cat, same values
+    mixed = [T.part_of(T.part_of(t4, 1, i), 2, i % 2) for i in range(4)]
+    assert torch.equal(T.restack(mixed, 1), torch.stack([t4[:, i][:, :, i % 2] for i in range(4)], dim=1))
+    swapped = [parts[2], parts[1], parts[3], parts[4]]
+    assert torch.equal(T.restack(swapped, 1), torch.stack([t4[:, i][:, :, 1] for i in (1, 0, 2, 3)], dim=1))
