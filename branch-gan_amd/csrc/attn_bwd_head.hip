@@ -321,12 +321,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void branch_attn_bwd_head_kernel(Head
       // ---- dK / dV of slot idx: eight branch points at a time (eight lanes each, DH / 8 features a lane), over the member nodes ----
       constexpr int PER = DH / 8;
       const int sub = lane & 7;
-      const T* kslot = nullptr;
-      const T* vslot = nullptr;
-      T* dkslot = nullptr;
-      T* dvslot = nullptr;
-      for (int sidx = 0; sidx < sh.n_slots; ++sidx)
-        if (sidx == idx) { kslot = (const T*)a.k_slots[sidx]; vslot = (const T*)a.v_slots[sidx]; dkslot = (T*)a.dk_slots[sidx]; dvslot = (T*)a.dv_slots[sidx]; }
+      const int su = __builtin_amdgcn_readfirstlane(idx);           // the wave's slot: scalar loads of its four pointers
+      const T* kslot = (const T*)a.k_slots[su];
+      const T* vslot = (const T*)a.v_slots[su];
+      T* dkslot = (T*)a.dk_slots[su];
+      T* dvslot = (T*)a.dv_slots[su];
       for (int k0 = 0; k0 < sh.K; k0 += 8) {
         const int kq = k0 + (lane >> 3);
         const bool valid = kq < sh.K;

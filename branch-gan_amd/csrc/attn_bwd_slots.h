@@ -61,12 +61,13 @@ __device__ __forceinline__ void bwd_slot_rows(const AttnArgs& a, int* s_members 
   const bg_attn_shape& sh = a.sh;
   const int b = bh / sh.H, hh = bh % sh.H;
   const int tid = threadIdx.x, sub = tid % LPR, lane = tid & 63, wave = tid >> 6;
-  const T* kslot = nullptr;
-  const T* vslot = nullptr;
-  T* dkslot = nullptr;
-  T* dvslot = nullptr;
-  for (int sidx = 0; sidx < sh.n_slots; ++sidx)
-    if (sidx == slot) { kslot = (const T*)a.k_slots[sidx]; vslot = (const T*)a.v_slots[sidx]; dkslot = (T*)a.dk_slots[sidx]; dvslot = (T*)a.dv_slots[sidx]; }
+  // the slot is the workgroup's: its four pointers are scalar loads from the argument buffer (a loop over the table that
+  // compared every index with `slot` became a vector load per pointer, one round trip before the first row could be asked for)
+  const int su = __builtin_amdgcn_readfirstlane(slot);
+  const T* kslot = (const T*)a.k_slots[su];
+  const T* vslot = (const T*)a.v_slots[su];
+  T* dkslot = (T*)a.dk_slots[su];
+  T* dvslot = (T*)a.dv_slots[su];
 
   [[maybe_unused]] DropKeys drop;
   if constexpr (DROP) drop = drop_keys(a, bh);
