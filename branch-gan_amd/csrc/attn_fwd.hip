@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256, (PF ? (DH * sizeof(T) <= 128 ? 2 : 1) : (DH * 
   // key and value rows of an entry in ONE round of loads where the registers allow (path -> pointer -> key -> value was four
   // round trips an entry), the first two entries of the wave in the SAME round (path tables up to 8 entries: all of them)
   // (Dh 256 bf16 with ONE entry's rows together was tried: the 128 registers push the full-range kernel back into spilling,
-  // c4 root causal 29.7 -> 35.1 us, tree pass 43.7 -> 50.7 us)
+  // c4 root causal 29.7 -> 35.1 us, tree pass 43.7 -> 50.7 us; in the key-split kernel alone, whose branch steps spend 4.5 us on
+  // every entry - benchmarks/probes/attn_fwd_trace.py c4 - it fits (450 registers) but the c4 step did not get faster, 73.4 ms,
+  // and the bench's side replay of the recorded forward launches did not finish within its time limit with it: not understood,
+  // not shipped)
   constexpr bool TOGETHER = DH * sizeof(T) <= 256;
   constexpr int NPRE = TOGETHER ? 2 : 0;
   const bool path_here = !KVSPLIT || split == n_splits - 1;          // key-range split: the branch keys ride with the last split
