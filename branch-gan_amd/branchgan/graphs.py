@@ -114,6 +114,15 @@ def _settle_collectives():
         time.sleep(extra / 1e3)
 
 
+def _both_models_large(model, hidden=1024):
+    """Generator and discriminator both at least `hidden` wide (see GraphedTrainStep.__init__: stream-K GEMMs side by side)."""
+    widths = []
+    for part in (model.generator, model.discriminator):
+        cfg = next((m.config for m in part.modules() if hasattr(getattr(m, "config", None), "hidden_size")), None)
+        widths.append(cfg.hidden_size if cfg is not None else 0)
+    return min(widths) >= hidden
+
+
 class GraphedTrainStep:
     """`warmup` eager steps lay out the arenas, caches and workspaces; they run on `example_ids` and, unless
     restore_after_warmup=False, parameters, optimizer state (moments, step counts) and LR schedulers are put back to what
@@ -140,6 +149,15 @@ class GraphedTrainStep:
         # one rank: the discriminator's backward graph is replayed on a second stream BESIDE the generator's (see _step)
         self._overlap = (not self._defer_d) if os.environ.get("BRANCHGAN_OVERLAP_BWD") is None else os.environ["BRANCHGAN_OVERLAP_BWD"] == "1"
         if not hasattr(torch._C, "_cuda_clearCublasWorkspaces"):      # no way to give each graph its own GEMM workspace: one after the other
+            self._overlap = False
+        if self._overlap and os.environ.get("BRANCHGAN_OVERLAP_BWD") is None and _both_models_large(model):
+            # Nearly every hipBLASLt kernel is a stream-K kernel (SK3): workgroups that spin on partial tiles of their siblings, i.e.
+            # that count on the whole grid being resident.  Two of them from two streams, each with one 256 x 256 workgroup per CU,
+            # can hold half the chip each and wait for the other half for ever.  Seen at configs[3] only (generator h 2048 beside
+            # discriminator h 1024: a replay that never ends, 2 runs of 7 with one kernel variant, every run with another, none of
+            # ~25 with the shipped kernels; 0 of 8 in turn), never at configs[1] / [2] in thousands of steps (one of the two models'
+            # GEMMs is small there).  Two large models replay their backward graphs in turn (configs[3]: 77.8 ms instead of 73.2);
+            # BRANCHGAN_OVERLAP_BWD=1 asks for side by side regardless.
             self._overlap = False
         self.nan_flag = torch.zeros((), dtype=torch.bool, device=dev)
         # exponential noise of the race techniques: persistent tensors, one per sampling call of a step, refreshed before a replay

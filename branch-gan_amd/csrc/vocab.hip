@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void softmax_stats_bwd_kernel(const T* logits,
   // One chunk per iteration here, unlike the forward kernel: the four-at-a-time form of this loop (loads first) was
   // bit-identical and 2x faster at 256 rows, but with it the configs[3] step stopped making progress whenever the two backward
   // graphs were replayed side by side (this kernel beside the discriminator's GEMMs; fine alone, fine with the graphs in
-  // turn) - not understood, so not shipped.
+  // turn) - not understood then, so not shipped; the likeliest reading since (two stream-K GEMMs of the two streams waiting for
+  // each other's workgroups, with this kernel only moving the timing) is in DESIGN §5 item 12, and steps of two large models no
+  // longer replay side by side.
   constexpr int64_t CH = 256 * VEC;
   int64_t cb = vbegin;
   for (; cb < V; cb += CH) guarded(cb);
