@@ -158,3 +158,20 @@ def test_restack_joins_runs_of_nested_slices_with_one_cat():
     assert torch.equal(T.restack(mixed, 1), torch.stack([t4[:, i][:, :, i % 2] for i in range(4)], dim=1))
     swapped = [parts[2], parts[1], parts[3], parts[4]]
     assert torch.equal(T.restack(swapped, 1), torch.stack([t4[:, i][:, :, 1] for i in (1, 0, 2, 3)], dim=1))
+
+
+def test_two_large_models_do_not_replay_their_backward_graphs_side_by_side():
+    """graphs._both_models_large: the guard against two stream-K GEMMs of two streams waiting for each other."""
+    from types import SimpleNamespace
+    from branchgan import graphs
+
+    def part(h):
+        m = torch.nn.Linear(2, 2)
+        m.config = SimpleNamespace(hidden_size=h)
+        return torch.nn.Sequential(m)
+
+    pair = lambda g, d: SimpleNamespace(generator=part(g), discriminator=part(d))
+    assert graphs._both_models_large(pair(2048, 1024))              # configs[3]
+    assert not graphs._both_models_large(pair(768, 768))            # configs[1]
+    assert not graphs._both_models_large(pair(1024, 128))           # configs[2]
+    assert not graphs._both_models_large(SimpleNamespace(generator=torch.nn.Linear(2, 2), discriminator=part(4096)))
